@@ -1,0 +1,295 @@
+/*
+ * ovla.h -- C-ABI of libovla_hip.so: the MI355X (gfx950) kernels behind the OpenVLA-OFT
+ * parallel-decoding action-chunk forward/backward path.
+ *
+ * The reference (ciccio42/openvla-oft) has NO native interface for this path: every FLOP is delegated to
+ * PyTorch / timm / transformers / peft.  Each entry point below therefore cites the reference
+ * *Python call site* whose arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no torch types.  All device buffers are caller-owned.
+ *  - every op is `int ovla_<op>(const ovla_<op>_args*, void* hip_stream)`; returns 0 or a negative OVLA_E* code,
+ *    `ovla_last_error()` returns a thread-local message.  Nothing is allocated, nothing synchronises the host;
+ *    all kernels are stream-ordered on the given stream.
+ *  - bf16 tensors are passed as `const void*` holding IEEE bfloat16 bit patterns; row-major; leading dimensions
+ *    ("ld*") are in ELEMENTS.
+ *  - "rows" of a token matrix are flattened (batch, position): row = b * S + s.
+ */
+#ifndef OVLA_H_
+#define OVLA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OVLA_OK 0
+#define OVLA_EINVAL (-1)  /* malformed arguments (shape/alignment/null) */
+#define OVLA_EARCH (-2)   /* device is not gfx950 */
+#define OVLA_ELAUNCH (-3) /* HIP launch / runtime error */
+
+#define OVLA_ABI_VERSION 1
+
+const char* ovla_last_error(void);
+int ovla_abi_version(void);
+/* Checks that `device` is a gfx950 part; returns OVLA_OK / OVLA_EARCH / OVLA_ELAUNCH. */
+int ovla_check_device(int device);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = epilogue( A[M,K] . B[N,K]^T  (+ A2[M,K2] . B2[N,K2]^T) )          bf16 in, fp32 accumulate
+ *
+ * Replaces every nn.Linear on the path:
+ *   Llama q/k/v/o/gate/up/down  (transformers LlamaDecoderLayer, call site prismatic/extern/hf/modeling_prismatic.py:632-643)
+ *   timm Block qkv/proj/fc1/fc2 and patch_embed-as-GEMM (call site modeling_prismatic.py:201-227)
+ *   PrismaticProjector fc1/fc2/fc3 (modeling_prismatic.py:250-262), ProprioProjector / NoisyActionProjector
+ *   (prismatic/models/projectors.py:19-24,44-49), MLPResNet fc1 / block Linear (prismatic/models/action_heads.py:72-81),
+ *   FiLM scale/shift (prismatic/models/film_vit_wrapper.py:65-67),
+ * and, through the (A2,B2) "K-extension", peft's LoRA update  y += (alpha/r) * B(A x)  (vla-scripts/finetune.py:862-871):
+ * A2 = scaled t = s * x A^T  [M, G*r],  B2 = stacked LoRA-B [N, r]; the column block of A2 used by an output tile is
+ * (n0 / k2_group_n) * K2, so fused q|k|v and gate|up linears share one launch.
+ * Because frozen weights are kept both as W [out,in] and W^T [in,out] in HBM, the same "NT" kernel computes the
+ * backward data gradient dX = dY . W (A = dY, B = W^T).
+ *
+ * Epilogue order (each step rounds to bf16 like the reference's separate PyTorch ops do):
+ *   v = acc;  v += bias[n];  [C_pre = v];  v = act(v);  v *= colscale[n];  v += residual[m,n];
+ *   v = v * (1 + film_gamma[m / film_rows, n]) + film_beta[...]  ->  C
+ * Requirements: K % 8 == 0, K2 % 8 == 0, N % 8 == 0, ld* % 8 == 0, 16-byte aligned base pointers.
+ * split_k > 1 needs `workspace` of ovla_gemm_workspace_bytes() bytes.
+ */
+enum { OVLA_ACT_NONE = 0, OVLA_ACT_GELU = 1, OVLA_ACT_RELU = 2, OVLA_ACT_SILU = 3, OVLA_ACT_GELU_TANH = 4 };
+
+typedef struct {
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  const void* A2; int64_t lda2;  /* optional K-extension (LoRA) */
+  const void* B2; int64_t ldb2;
+  void* C; int64_t ldc;          /* bf16 [M,N] */
+  void* C_pre;                   /* optional bf16 [M,N] (ldc): value before the activation (saved for backward) */
+  const void* bias;              /* optional bf16 [N] */
+  const void* colscale;          /* optional bf16 [N]  (timm LayerScale) */
+  const void* residual; int64_t ldr; /* optional bf16 [M,N] */
+  const void* film_gamma;        /* optional bf16 [M/film_rows, N]  (FiLM) */
+  const void* film_beta;
+  int32_t film_rows;
+  int32_t M, N, K, K2;
+  int32_t k2_group_n;            /* 0: A2 column offset 0 for every tile */
+  int32_t act;
+  int32_t split_k;               /* <=1: none */
+  int32_t tile;                  /* 0: auto; otherwise forces a tile configuration (tests / tuning) */
+  void* workspace;               /* fp32 [split_k, M, N] when split_k > 1 */
+} ovla_gemm_args;
+
+int64_t ovla_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
+int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * "TN" GEMM (weight gradients)   C[P,Q] (+)= alpha * X[M,P]^T . Y[M,Q]     bf16 in, fp32 accumulate
+ * Replaces autograd's weight-gradient matmuls for the trainable tensors: LoRA A/B (peft, finetune.py:862-871),
+ * L1RegressionActionHead / ProprioProjector / NoisyActionProjector / FiLM Linears (finetune.py:894-932).
+ * out_mode 0: fp32 atomicAdd into C (C must hold the running sum; the M range is split over workgroups)
+ *          1: fp32 store    2: bf16 store   (modes 1/2: no M split)
+ */
+typedef struct {
+  const void* X; int64_t ldx;
+  const void* Y; int64_t ldy;
+  void* C; int64_t ldc;
+  int32_t M, P, Q;
+  float alpha;
+  int32_t out_mode;
+} ovla_gemm_tn_args;
+int ovla_gemm_tn_bf16(const ovla_gemm_tn_args* a, void* stream);
+
+/* column sums  out[n] (+)= sum_m X[m,n]   (bias gradients).  out fp32, atomic accumulate. */
+typedef struct { const void* X; int64_t ldx; float* out; int32_t M, N; } ovla_colsum_args;
+int ovla_colsum_bf16(const ovla_colsum_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Attention (no KV paging; whole short context; K/V tiles staged through LDS)
+ *   O[b,s,h,:] = softmax_k( scale * Q[b,s,h,:] . K[b,k,h,:]  + mask ) V[b,k,h,:]
+ * Replaces F.scaled_dot_product_attention inside timm Attention (ViT, unmasked) and inside the transformers-fork
+ * LlamaAttention (bidirectional + key padding: reference pyproject.toml:50, modeling_prismatic.py:742; `causal`
+ * selects the stock lower-triangular mask).  Key padding is right padding only (reference collator
+ * prismatic/util/data_utils.py:115): keys >= kv_len[b] are masked; kv_len == NULL means all S keys.
+ * Q/K/V/O are addressed as  base + (b*S + s) * row_stride + h * head_dim  (elements), so the fused QKV GEMM output is
+ * consumed in place.  head_dim in {64, 72, 128}.  lse: fp32 [B, H, S] (natural-log sum-exp of the scaled scores).
+ */
+typedef struct {
+  const void* Q; const void* K; const void* V; int64_t q_stride, k_stride, v_stride;
+  void* O; int64_t o_stride;
+  float* lse;
+  const int32_t* kv_len;  /* optional [B] */
+  int32_t B, H, S, head_dim;
+  int32_t causal;
+  float scale;
+} ovla_attn_fwd_args;
+int ovla_attn_fwd(const ovla_attn_fwd_args* a, void* stream);
+
+typedef struct {
+  const void* Q; const void* K; const void* V; int64_t q_stride, k_stride, v_stride;
+  const void* O; const void* dO; int64_t o_stride, do_stride;
+  const float* lse;
+  float* delta;            /* workspace fp32 [B,H,S]: rowsum(dO * O) */
+  void* dQ; void* dK; void* dV; int64_t dq_stride, dk_stride, dv_stride;
+  const int32_t* kv_len;
+  int32_t B, H, S, head_dim;
+  int32_t causal;
+  float scale;
+} ovla_attn_bwd_args;
+int ovla_attn_bwd(const ovla_attn_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Normalisation.  RMSNorm: transformers LlamaRMSNorm (fp32 math, eps 1e-5).  LayerNorm: timm blocks (eps 1e-6) and
+ * MLPResNet (action_heads.py:64,69, eps 1e-5).  x/y bf16 [rows, dim]; weight/bias bf16 [dim] (bias NULL for RMS).
+ * rstd (and mean) fp32 [rows] are saved for the backward.  The backward returns dx (bf16); dw/db (fp32, atomic
+ * accumulate) only when non-NULL (they are frozen on the LoRA path except in the action head).
+ * If `dx_accum` != 0 the backward ADDS into dx (residual-stream gradient) instead of overwriting it.
+ */
+typedef struct {
+  const void* x; void* y; const void* weight; const void* bias;
+  float* mean; float* rstd;
+  int32_t rows, dim; float eps; int32_t is_rms;
+} ovla_norm_fwd_args;
+int ovla_norm_fwd(const ovla_norm_fwd_args* a, void* stream);
+
+typedef struct {
+  const void* x; const void* dy; const void* weight;
+  const float* mean; const float* rstd;
+  void* dx; float* dweight; float* dbias;
+  int32_t rows, dim; int32_t is_rms; int32_t dx_accum;
+} ovla_norm_bwd_args;
+int ovla_norm_bwd(const ovla_norm_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * RoPE, in place on the q and k heads of a fused [rows, ld] buffer (HF "rotate_half" convention; position = row % S).
+ * cos/sin tables are bf16 [S, head_dim/2], built once by ovla_rope_table (fp32 angles, then cast to bf16 exactly as
+ * transformers LlamaRotaryEmbedding does before apply_rotary_pos_emb).  `inverse` applies the transposed rotation
+ * (backward).  n_heads = q heads + k heads, contiguous from column 0.
+ */
+int ovla_rope_table(void* cos_table, void* sin_table, int32_t S, int32_t head_dim, float theta, void* stream);
+typedef struct {
+  void* qk; int64_t ld; int32_t rows, S, n_heads, head_dim;
+  const void* cos_table; const void* sin_table; int32_t inverse;
+} ovla_rope_args;
+int ovla_rope(const ovla_rope_args* a, void* stream);
+
+/* SwiGLU:  h = silu(g) * u  with gu = [g | u] as [rows, 2F];  backward writes dgu from dh and gu. */
+typedef struct { const void* gu; void* h; int32_t rows, F; } ovla_swiglu_fwd_args;
+int ovla_swiglu_fwd(const ovla_swiglu_fwd_args* a, void* stream);
+typedef struct { const void* gu; const void* dh; void* dgu; int32_t rows, F; } ovla_swiglu_bwd_args;
+int ovla_swiglu_bwd(const ovla_swiglu_bwd_args* a, void* stream);
+
+/* activation backward:  dz = dh * act'(z)   (z = saved pre-activation), elementwise on [n] bf16 */
+typedef struct { const void* z; const void* dh; void* dz; int64_t n; int32_t act; } ovla_act_bwd_args;
+int ovla_act_bwd(const ovla_act_bwd_args* a, void* stream);
+
+/* y = alpha*x (+ y if accum)   and friends: small elementwise helpers on bf16 buffers */
+typedef struct { const void* a; const void* b; void* out; int64_t n; } ovla_add_args;
+int ovla_add_bf16(const ovla_add_args* a, void* stream);  /* out = a + b (b may be NULL: copy) */
+typedef struct { const void* x; const void* scale; void* out; int32_t rows, dim; } ovla_colscale_args;
+int ovla_colscale_bf16(const ovla_colscale_args* a, void* stream); /* out[m,n] = x[m,n]*scale[n] */
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Vision front end.
+ * im2col for the 14x14/stride-14 patch embedding (timm PatchEmbed Conv2d as GEMM): pixel_values bf16 NCHW
+ * [B, C_total, H, W], channels [c0, c0+3) -> rows [B*gh*gw, ldo] with K = 3*p*p real columns (c, py, px) and zero pad.
+ */
+typedef struct { const void* pixels; void* out; int64_t ldo; int32_t B, C_total, c0, H, W, patch; } ovla_im2col_args;
+int ovla_im2col(const ovla_im2col_args* a, void* stream);
+
+/* tokens[b, pre + i, :] = patches[b, i, :] + pos[i, :] ;  tokens[b, j, :] = prefix[j, :]  (cls / register tokens)
+ * (timm VisionTransformer._pos_embed with no_embed_class=True) */
+typedef struct { const void* patches; const void* pos; const void* prefix; void* tokens; int32_t B, n_patches, n_prefix, dim; } ovla_vit_embed_args;
+int ovla_vit_embed(const ovla_vit_embed_args* a, void* stream);
+/* strided row copy: dst[b, i, dst_col0 : dst_col0+dim] = src[b, src_row0 + i, :]   (drop prefix tokens + feature concat,
+ * modeling_prismatic.py:221-227); `accumulate` adds instead (used by the backward). */
+typedef struct {
+  const void* src; void* dst; int32_t B, rows, dim;
+  int64_t src_batch_stride, src_row0, src_ld, dst_batch_stride, dst_row0, dst_ld, dst_col0; int32_t accumulate;
+} ovla_copy_rows_args;
+int ovla_copy_rows(const ovla_copy_rows_args* a, void* stream);
+
+/* FiLM modulation backward helpers / mean pooling:  out[b,:] = mean_{i<len[b] valid rows} x[b, i, :]  */
+typedef struct { const void* x; const uint8_t* row_mask; void* out; int32_t B, L, dim; } ovla_masked_mean_args;
+int ovla_masked_mean(const ovla_masked_mean_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Multimodal sequence assembly (modeling_prismatic.py:571-629): one pass writes
+ *   out[b, 0]            = embed[ids[b,0]]
+ *   out[b, 1 .. P]       = patches[b, :]            (P = projected patches + proprio (+ timestep) tokens)
+ *   out[b, P+1+i]        = action_mask[b,1+i] ? (noisy ? noisy[b, slot] : 0) : embed[ids[b, 1+i]]
+ * action_mask is computed on device from labels exactly as train_utils.get_current_action_mask | get_next_actions_mask
+ * (cumsum of labels != -100, labels > 31743); `action_index` receives, per batch row, the A sequence positions
+ * (in the assembled sequence) of the action slots, used by ovla_gather_rows for the shift-by-one hidden gather.
+ */
+typedef struct {
+  const int64_t* ids; const int64_t* labels;   /* [B, L] */
+  const void* embed_table;                      /* bf16 [V, D] */
+  const void* patches;                          /* bf16 [B, P, D] */
+  const void* noisy;                            /* optional bf16 [B, A, D] */
+  void* out;                                    /* bf16 [B, P+L, D] */
+  int32_t* action_pos;                          /* optional int32 [B, A]: text-relative index of each action slot */
+  int32_t B, L, P, D, A, vocab;
+  int32_t ignore_index, action_token_begin, action_dim;
+} ovla_assemble_args;
+int ovla_assemble_multimodal(const ovla_assemble_args* a, void* stream);
+
+/* dst[i, :] = src[index[i], :]  /  scatter-add backward  */
+typedef struct { const void* src; const int32_t* index; void* dst; int32_t n, dim; int64_t src_ld, dst_ld; int32_t scatter_add; } ovla_gather_rows_args;
+int ovla_gather_rows(const ovla_gather_rows_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * L1 action head tail (prismatic/models/action_heads.py:69-81, finetune.py:400):
+ *   pred[m, :adim] = x[m,:] . W[adim, dim]^T + b ;  loss = mean |pred - target|
+ * and its backward (dpred = sign(pred-target)/count * dloss -> dx, dW, db).  The wide layers of the head run on
+ * ovla_gemm_bf16 / ovla_norm_*; this is the N = ACTION_DIM tail that does not fit an MFMA tile.
+ */
+typedef struct {
+  const void* x; const void* W; const void* b; void* pred;   /* bf16 */
+  const void* target; float* loss_sum;                        /* optional: accumulates sum |pred-target| (or squared, mse) */
+  int32_t rows, dim, adim;
+  int32_t mse;
+} ovla_head_out_fwd_args;
+int ovla_head_out_fwd(const ovla_head_out_fwd_args* a, void* stream);
+typedef struct {
+  const void* x; const void* W; const void* pred; const void* target;
+  float dloss_scale;            /* dloss / (rows*adim) */
+  int32_t mse;                  /* 0: L1 (sign), 1: MSE (2*(pred-target)) */
+  void* dx; float* dW; float* db;
+  int32_t rows, dim, adim;
+} ovla_head_out_bwd_args;
+int ovla_head_out_bwd(const ovla_head_out_bwd_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fused AdamW over a flat parameter buffer (torch.optim.AdamW as called at finetune.py:952: betas (0.9,0.999),
+ * eps 1e-8, weight_decay 0.01).  bf16 variant reproduces torch's per-op bf16 rounding sequence
+ * (param *= 1-lr*wd; m.lerp_(g,1-b1); v = v*b2 + (1-b2) g*g; denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) m/denom)
+ * so results are bit-identical to torch on the same inputs.  grads are fp32 master-accumulated here and are rounded to
+ * the parameter dtype first (what autograd would have stored).  grad_scale multiplies the gradient (1/world, 1/accum).
+ */
+typedef struct {
+  void* param; void* exp_avg; void* exp_avg_sq;   /* bf16 or fp32 (is_bf16) */
+  const float* grad;
+  int64_t n; int32_t is_bf16; int32_t step;       /* step >= 1 (after increment, as torch) */
+  double lr, beta1, beta2, eps, weight_decay;     /* Python floats, combined in double like torch/optim/adamw.py */
+  float grad_scale;
+} ovla_adamw_args;
+int ovla_adamw(const ovla_adamw_args* a, void* stream);
+
+/* fp32 -> bf16 convert with scale (publishes .grad views), and fill */
+typedef struct { const float* src; void* dst; int64_t n; float scale; } ovla_cvt_args;
+int ovla_cvt_f32_to_bf16(const ovla_cvt_args* a, void* stream);
+int ovla_cvt_bf16_to_f32(const void* src, float* dst, int64_t n, float scale, void* stream);
+
+/* transpose bf16 [rows, cols] -> [cols, rows] (W^T copies of the frozen weights, LoRA A^T/B^T refresh) */
+typedef struct { const void* src; void* dst; int32_t rows, cols; int64_t lds, ldd; } ovla_transpose_args;
+int ovla_transpose_bf16(const ovla_transpose_args* a, void* stream);
+
+/* self-test hook used by tests/: dumps the MFMA / transposed-LDS-read / LDS-DMA lane layouts the kernels rely on.
+ * out: fp32 [4, 64, 16] device;  src: bf16 [512] device holding 0..511. */
+int ovla_selftest_layouts(float* out, const void* src, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVLA_H_ */

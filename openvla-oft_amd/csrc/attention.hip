@@ -1,0 +1,544 @@
+// attention.hip -- flash-style attention forward / backward for the short (S <= ~1.2k) OpenVLA-OFT context on gfx950.
+//
+// Replaces F.scaled_dot_product_attention in timm Attention (ViT: unmasked, head_dim 64 / 72) and in the
+// transformers-fork LlamaAttention (head_dim 128; bidirectional + right key padding, or causal).  No KV paging: the
+// whole context streams through LDS in 64-key tiles.
+//
+// Lane mapping (all three kernels): scores are computed TRANSPOSED, S^T = K . Q^T with mfma_f32_16x16x32_bf16, so the
+// query (forward, dQ) or key (dK/dV) index sits on the lane (lane & 15) and the 4 accumulator registers x 4 lane
+// groups hold the other index.  Consequences:
+//   * softmax statistics, the LSE and the O / dQ / dK / dV rescale are lane-local (two xor-shuffles per row reduce);
+//   * P (and dS) leave the accumulators already shaped as the NEXT MFMA's B operand: the contraction index of the
+//     second product is simply taken in the permuted order {16t+4g+j} the accumulator presents it in, and the other
+//     operand (V, K, dO or Q, read TRANSPOSED from the row-major LDS tile by ds_read_b64_tr_b16) follows the same
+//     permutation -- no LDS round trip, no cross-lane traffic for P.
+// K/V (or Q/dO) tiles are register-staged (global_load_dwordx4 issued one tile ahead, written to LDS after the barrier)
+// into rows of head_dim_padded + 16 elements: that stride makes both the ds_read_b128 row reads and the transposed
+// reads bank-conflict free for head_dim 128.
+#include "common.h"
+
+namespace {
+
+constexpr int BQ = 64;   // rows per workgroup (4 waves x 16)
+constexpr int BKV = 64;  // keys per LDS tile
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+struct AttnParams {
+  const bf16_bits *Q, *K, *V, *O, *dO;
+  bf16_bits *Oout, *dQ, *dK, *dV;
+  int64_t q_stride, k_stride, v_stride, o_stride, do_stride, dq_stride, dk_stride, dv_stride;
+  float* lse;
+  const float* lse_in;
+  float* delta;
+  const int32_t* kv_len;
+  int B, H, S, hd, causal;
+  float scale;
+};
+
+OVLA_DEV bf16x4_bits lds_tr16(const bf16_bits* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_bits*)p);
+}
+
+// Transposed 16(col) x 8(contraction slot) fragment: slots jj<4 -> rows row0+4g+jj, jj>=4 -> rows row0+16+4g+(jj-4).
+OVLA_DEV bf16x8_bits tr_frag(const bf16_bits* tile, int row0, int col0, int stride, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const bf16_bits* a0 = tile + (row0 + 4 * g + (i >> 2)) * stride + col0 + 4 * (i & 3);
+  const bf16x4_bits lo = lds_tr16(a0);
+  const bf16x4_bits hi = lds_tr16(a0 + 16 * stride);
+  return bf16x8_bits{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+OVLA_DEV bf16x8_bits row_frag(const bf16_bits* tile, int row, int col0, int stride) {
+  return *reinterpret_cast<const bf16x8_bits*>(tile + row * stride + col0);
+}
+
+OVLA_DEV bf16x8_bits zero8() { return bf16x8_bits{0, 0, 0, 0, 0, 0, 0, 0}; }
+
+// global row fragment: 8 elements at column col of row `row` (clamped), zero beyond hd
+OVLA_DEV bf16x8_bits gload8(const bf16_bits* base, int64_t stride, int row, int col, int hd) {
+  if (col >= hd) return zero8();
+  return *reinterpret_cast<const bf16x8_bits*>(base + (int64_t)row * stride + col);
+}
+
+template <int DP>
+struct TileStage {
+  static constexpr int CH = DP / 8;              // 16-byte chunks per row
+  static constexpr int PER_THREAD = BKV * CH / 256;
+  static constexpr int STRIDE = DP + 16;
+  bf16x8_bits r[PER_THREAD];
+  OVLA_DEV void load(const bf16_bits* base, int64_t stride, int row0, int row_last, int hd, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int id = tid + 256 * i;
+      const int rr = id / CH, ch = id % CH;
+      int gr = row0 + rr;
+      gr = gr < row_last ? gr : row_last;
+      r[i] = gload8(base, stride, gr, ch * 8, hd);
+    }
+  }
+  OVLA_DEV void store(bf16_bits* tile, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int id = tid + 256 * i;
+      const int rr = id / CH, ch = id % CH;
+      *reinterpret_cast<bf16x8_bits*>(tile + rr * STRIDE + ch * 8) = r[i];
+    }
+  }
+};
+
+OVLA_DEV short f2bf_s(float f) { return (short)f2bf(f); }
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int DP>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+  constexpr int KS = DP / 32;   // contraction steps over head_dim
+  constexpr int DT = DP / 16;   // output d tiles
+  constexpr int STRIDE = DP + 16;
+  __shared__ __attribute__((aligned(16))) bf16_bits Ks[BKV * STRIDE];
+  __shared__ __attribute__((aligned(16))) bf16_bits Vs[BKV * STRIDE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQ;
+  const int qrow = q0 + wave * 16 + (lane & 15);
+  const int qrow_c = qrow < p.S ? qrow : p.S - 1;
+  const int kvlen = p.kv_len ? p.kv_len[b] : p.S;
+  int kv_end = kvlen < p.S ? kvlen : p.S;
+  if (p.causal) kv_end = kv_end < (q0 + BQ) ? kv_end : (q0 + BQ);
+  const int ntiles = (kv_end + BKV - 1) / BKV;
+
+  const bf16_bits* Qb = p.Q + (int64_t)b * p.S * p.q_stride + (int64_t)h * p.hd;
+  const bf16_bits* Kb = p.K + (int64_t)b * p.S * p.k_stride + (int64_t)h * p.hd;
+  const bf16_bits* Vb = p.V + (int64_t)b * p.S * p.v_stride + (int64_t)h * p.hd;
+
+  bf16x8_bits qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) qf[s] = gload8(Qb, p.q_stride, qrow_c, 32 * s + 8 * g, p.hd);
+
+  f32x4 accO[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) accO[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sl2 = p.scale * LOG2E;
+
+  TileStage<DP> kst, vst;
+  if (ntiles > 0) {
+    kst.load(Kb, p.k_stride, 0, p.S - 1, p.hd, tid);
+    vst.load(Vb, p.v_stride, 0, p.S - 1, p.hd, tid);
+  }
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();
+    kst.store(Ks, tid);
+    vst.store(Vs, tid);
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      kst.load(Kb, p.k_stride, (t + 1) * BKV, p.S - 1, p.hd, tid);
+      vst.load(Vb, p.v_stride, (t + 1) * BKV, p.S - 1, p.hd, tid);
+    }
+    // S^T = K . Q^T : accS[nt][j] = S[q = lane&15][key = 16 nt + 4 g + j]
+    f32x4 accS[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      accS[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        accS[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, nt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), qf[s],
+                                                           accS[nt], 0, 0, 0);
+    }
+    const int kbase = t * BKV;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = kbase + nt * 16 + 4 * g + j;
+        const bool ok = key < kvlen && (!p.causal || key <= qrow);
+        const float sv = ok ? accS[nt][j] * sl2 : -INFINITY;
+        accS[nt][j] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+    float psum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float pv = __builtin_amdgcn_exp2f(accS[nt][j] - m_safe);
+        accS[nt][j] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accO[d][j] *= alpha;
+    // O^T += V^T . P^T, contraction slots (g, jj): jj<4 -> key 32 s2 + 4g + jj, jj>=4 -> key 32 s2 + 16 + 4g + jj-4
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8_bits pf;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pf[j] = f2bf_s(accS[2 * s2][j]);
+        pf[4 + j] = f2bf_s(accS[2 * s2 + 1][j]);
+      }
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        accO[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vs, 32 * s2, d * 16, STRIDE, lane), pf, accO[d], 0, 0, 0);
+    }
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
+  if (qrow < p.S) {
+    bf16_bits* Ob = p.Oout + ((int64_t)b * p.S + qrow) * p.o_stride + (int64_t)h * p.hd;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const int col = d * 16 + 4 * g;
+      if (col < p.hd) {
+        bf16x4_bits o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f2bf_s(accO[d][j] * inv_l);
+        *reinterpret_cast<bf16x4_bits*>(Ob + col) = o;
+      }
+    }
+    if (g == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.S + qrow] = m_run * LN2 + __logf(l_run);
+  }
+}
+
+// delta[b,h,s] = sum_d dO * O      (16 lanes per (row, head))
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
+  const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int sub = threadIdx.x & 15;
+  const int64_t total = (int64_t)p.B * p.S * p.H;
+  float s = 0.f;
+  int64_t row = 0;
+  int h = 0;
+  if (item < total) {
+    row = item / p.H;
+    h = (int)(item % p.H);
+    const bf16_bits* o = p.O + row * p.o_stride + (int64_t)h * p.hd;
+    const bf16_bits* d = p.dO + row * p.do_stride + (int64_t)h * p.hd;
+    for (int c = sub * 8; c < p.hd; c += 128) {
+      const bf16x8_bits ov = *reinterpret_cast<const bf16x8_bits*>(o + c);
+      const bf16x8_bits dv = *reinterpret_cast<const bf16x8_bits*>(d + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += bf2f((bf16_bits)ov[j]) * bf2f((bf16_bits)dv[j]);
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (item < total && sub == 0) {
+    const int64_t bb = row / p.S, ss = row % p.S;
+    p.delta[(bb * p.H + h) * p.S + ss] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dQ: one workgroup per 64-query block, loops over K/V tiles.
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
+  constexpr int KS = DP / 32, DT = DP / 16, STRIDE = DP + 16;
+  __shared__ __attribute__((aligned(16))) bf16_bits Ks[BKV * STRIDE];
+  __shared__ __attribute__((aligned(16))) bf16_bits Vs[BKV * STRIDE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQ;
+  const int qrow = q0 + wave * 16 + (lane & 15);
+  const int qrow_c = qrow < p.S ? qrow : p.S - 1;
+  const int kvlen = p.kv_len ? p.kv_len[b] : p.S;
+  int kv_end = kvlen < p.S ? kvlen : p.S;
+  if (p.causal) kv_end = kv_end < (q0 + BQ) ? kv_end : (q0 + BQ);
+  const int ntiles = (kv_end + BKV - 1) / BKV;
+
+  const bf16_bits* Qb = p.Q + (int64_t)b * p.S * p.q_stride + (int64_t)h * p.hd;
+  const bf16_bits* Kb = p.K + (int64_t)b * p.S * p.k_stride + (int64_t)h * p.hd;
+  const bf16_bits* Vb = p.V + (int64_t)b * p.S * p.v_stride + (int64_t)h * p.hd;
+  const bf16_bits* dOb = p.dO + (int64_t)b * p.S * p.do_stride + (int64_t)h * p.hd;
+
+  bf16x8_bits qf[KS], dof[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    qf[s] = gload8(Qb, p.q_stride, qrow_c, 32 * s + 8 * g, p.hd);
+    dof[s] = gload8(dOb, p.do_stride, qrow_c, 32 * s + 8 * g, p.hd);
+  }
+  const int64_t stat = ((int64_t)b * p.H + h) * p.S + qrow_c;
+  const float Lq = p.lse_in[stat] * LOG2E;
+  const float Dq = p.delta[stat];
+  const float sl2 = p.scale * LOG2E;
+
+  f32x4 accQ[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) accQ[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  TileStage<DP> kst, vst;
+  if (ntiles > 0) {
+    kst.load(Kb, p.k_stride, 0, p.S - 1, p.hd, tid);
+    vst.load(Vb, p.v_stride, 0, p.S - 1, p.hd, tid);
+  }
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();
+    kst.store(Ks, tid);
+    vst.store(Vs, tid);
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      kst.load(Kb, p.k_stride, (t + 1) * BKV, p.S - 1, p.hd, tid);
+      vst.load(Vb, p.v_stride, (t + 1) * BKV, p.S - 1, p.hd, tid);
+    }
+    f32x4 accS[4], accP[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      accS[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      accP[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        accS[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, nt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), qf[s],
+                                                           accS[nt], 0, 0, 0);
+        accP[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vs, nt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), dof[s],
+                                                           accP[nt], 0, 0, 0);
+      }
+    }
+    const int kbase = t * BKV;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = kbase + nt * 16 + 4 * g + j;
+        const bool ok = key < kvlen && (!p.causal || key <= qrow);
+        const float pv = ok ? __builtin_amdgcn_exp2f(accS[nt][j] * sl2 - Lq) : 0.f;
+        accS[nt][j] = pv * (accP[nt][j] - Dq);  // dS (unscaled)
+      }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8_bits dsf;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dsf[j] = f2bf_s(accS[2 * s2][j]);
+        dsf[4 + j] = f2bf_s(accS[2 * s2 + 1][j]);
+      }
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        accQ[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Ks, 32 * s2, d * 16, STRIDE, lane), dsf, accQ[d], 0, 0, 0);
+    }
+  }
+  if (qrow < p.S) {
+    bf16_bits* dQb = p.dQ + ((int64_t)b * p.S + qrow) * p.dq_stride + (int64_t)h * p.hd;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const int col = d * 16 + 4 * g;
+      if (col < p.hd) {
+        bf16x4_bits o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = f2bf_s(accQ[d][j] * p.scale);
+        *reinterpret_cast<bf16x4_bits*>(dQb + col) = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dK / dV: one workgroup per 64-key block (wave = 16 keys, key on the lane), loops over Q / dO tiles.
+template <int DP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
+  constexpr int KS = DP / 32, DT = DP / 16, STRIDE = DP + 16;
+  __shared__ __attribute__((aligned(16))) bf16_bits Qs[BQ * STRIDE];
+  __shared__ __attribute__((aligned(16))) bf16_bits dOs[BQ * STRIDE];
+  __shared__ float Ls[BQ], Ds[BQ];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * BKV;
+  const int krow = k0 + wave * 16 + (lane & 15);
+  const int krow_c = krow < p.S ? krow : p.S - 1;
+  const int kvlen = p.kv_len ? p.kv_len[b] : p.S;
+
+  const bf16_bits* Qb = p.Q + (int64_t)b * p.S * p.q_stride + (int64_t)h * p.hd;
+  const bf16_bits* Kb = p.K + (int64_t)b * p.S * p.k_stride + (int64_t)h * p.hd;
+  const bf16_bits* Vb = p.V + (int64_t)b * p.S * p.v_stride + (int64_t)h * p.hd;
+  const bf16_bits* dOb = p.dO + (int64_t)b * p.S * p.do_stride + (int64_t)h * p.hd;
+  const float* lse_b = p.lse_in + ((int64_t)b * p.H + h) * p.S;
+  const float* del_b = p.delta + ((int64_t)b * p.H + h) * p.S;
+
+  bf16x8_bits kf[KS], vf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    kf[s] = gload8(Kb, p.k_stride, krow_c, 32 * s + 8 * g, p.hd);
+    vf[s] = gload8(Vb, p.v_stride, krow_c, 32 * s + 8 * g, p.hd);
+  }
+  const float sl2 = p.scale * LOG2E;
+  f32x4 accK[DT], accV[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+    accK[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    accV[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool key_ok = krow < kvlen && krow < p.S;
+  const int nq = (p.S + BQ - 1) / BQ;
+  const int qt0 = p.causal ? (k0 / BQ) : 0;
+
+  TileStage<DP> qst, dst;
+  float lreg = 0.f, dreg = 0.f;
+  auto load_stats = [&](int qt) {
+    if (tid < BQ) {
+      int r = qt * BQ + tid;
+      r = r < p.S ? r : p.S - 1;
+      lreg = lse_b[r] * LOG2E;
+      dreg = del_b[r];
+    }
+  };
+  if (qt0 < nq) {
+    qst.load(Qb, p.q_stride, qt0 * BQ, p.S - 1, p.hd, tid);
+    dst.load(dOb, p.do_stride, qt0 * BQ, p.S - 1, p.hd, tid);
+    load_stats(qt0);
+  }
+  for (int qt = qt0; qt < nq; ++qt) {
+    __syncthreads();
+    qst.store(Qs, tid);
+    dst.store(dOs, tid);
+    if (tid < BQ) {
+      Ls[tid] = lreg;
+      Ds[tid] = dreg;
+    }
+    __syncthreads();
+    if (qt + 1 < nq) {
+      qst.load(Qb, p.q_stride, (qt + 1) * BQ, p.S - 1, p.hd, tid);
+      dst.load(dOb, p.do_stride, (qt + 1) * BQ, p.S - 1, p.hd, tid);
+      load_stats(qt + 1);
+    }
+    // S[q][key], dP[q][key] with key = lane&15, q = 16 mt + 4 g + j
+    f32x4 accS[4], accP[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      accS[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      accP[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        accS[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Qs, mt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), kf[s],
+                                                           accS[mt], 0, 0, 0);
+        accP[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(dOs, mt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), vf[s],
+                                                           accP[mt], 0, 0, 0);
+      }
+    }
+    const int qbase = qt * BQ;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ql = mt * 16 + 4 * g + j;
+        const int q = qbase + ql;
+        const bool ok = key_ok && q < p.S && (!p.causal || krow <= q);
+        const float pv = ok ? __builtin_amdgcn_exp2f(accS[mt][j] * sl2 - Ls[ql]) : 0.f;
+        accS[mt][j] = pv;                              // P
+        accP[mt][j] = pv * (accP[mt][j] - Ds[ql]);     // dS (unscaled)
+      }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8_bits pf, dsf;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pf[j] = f2bf_s(accS[2 * s2][j]);
+        pf[4 + j] = f2bf_s(accS[2 * s2 + 1][j]);
+        dsf[j] = f2bf_s(accP[2 * s2][j]);
+        dsf[4 + j] = f2bf_s(accP[2 * s2 + 1][j]);
+      }
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        accV[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(dOs, 32 * s2, d * 16, STRIDE, lane), pf, accV[d], 0, 0, 0);
+        accK[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Qs, 32 * s2, d * 16, STRIDE, lane), dsf, accK[d], 0, 0, 0);
+      }
+    }
+  }
+  if (krow < p.S) {
+    bf16_bits* dKb = p.dK + ((int64_t)b * p.S + krow) * p.dk_stride + (int64_t)h * p.hd;
+    bf16_bits* dVb = p.dV + ((int64_t)b * p.S + krow) * p.dv_stride + (int64_t)h * p.hd;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const int col = d * 16 + 4 * g;
+      if (col < p.hd) {
+        bf16x4_bits ok_, ov_;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ok_[j] = f2bf_s(accK[d][j] * p.scale);
+          ov_[j] = f2bf_s(accV[d][j]);
+        }
+        *reinterpret_cast<bf16x4_bits*>(dKb + col) = ok_;
+        *reinterpret_cast<bf16x4_bits*>(dVb + col) = ov_;
+      }
+    }
+  }
+}
+
+int check_common(int B, int H, int S, int hd, const char* who) {
+  if (!(B > 0 && H > 0 && S > 0)) {
+    ovla_set_error("%s: empty problem B=%d H=%d S=%d", who, B, H, S);
+    return OVLA_EINVAL;
+  }
+  if (!(hd == 64 || hd == 72 || hd == 128)) {
+    ovla_set_error("%s: head_dim %d not supported (64, 72, 128)", who, hd);
+    return OVLA_EINVAL;
+  }
+  return OVLA_OK;
+}
+
+inline bool stride_ok(int64_t s) { return (s % 8) == 0; }
+
+}  // namespace
+
+extern "C" int ovla_attn_fwd(const ovla_attn_fwd_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->Q && a->K && a->V && a->O, "ovla_attn_fwd: null pointer");
+  if (int rc = check_common(a->B, a->H, a->S, a->head_dim, "ovla_attn_fwd")) return rc;
+  OVLA_REQUIRE(stride_ok(a->q_stride) && stride_ok(a->k_stride) && stride_ok(a->v_stride) && (a->o_stride % 4) == 0,
+               "ovla_attn_fwd: row strides must be multiples of 8 elements");
+  OVLA_REQUIRE(aligned16(a->Q) && aligned16(a->K) && aligned16(a->V) && (((uintptr_t)a->O) & 7) == 0, "ovla_attn_fwd: alignment");
+  AttnParams p = {};
+  p.Q = (const bf16_bits*)a->Q; p.K = (const bf16_bits*)a->K; p.V = (const bf16_bits*)a->V; p.Oout = (bf16_bits*)a->O;
+  p.q_stride = a->q_stride; p.k_stride = a->k_stride; p.v_stride = a->v_stride; p.o_stride = a->o_stride;
+  p.lse = a->lse; p.kv_len = a->kv_len; p.B = a->B; p.H = a->H; p.S = a->S; p.hd = a->head_dim; p.causal = a->causal; p.scale = a->scale;
+  const dim3 grid(cdiv(a->S, BQ), a->H, a->B);
+  switch (a->head_dim) {
+    case 64: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, stream, p); break;
+    case 72: hipLaunchKernelGGL(attn_fwd_kernel<96>, grid, dim3(256), 0, stream, p); break;
+    default: hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, stream, p); break;
+  }
+  OVLA_CHECK_LAUNCH("ovla_attn_fwd");
+  return OVLA_OK;
+}
+
+extern "C" int ovla_attn_bwd(const ovla_attn_bwd_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->Q && a->K && a->V && a->O && a->dO && a->lse && a->delta && a->dQ && a->dK && a->dV, "ovla_attn_bwd: null pointer");
+  if (int rc = check_common(a->B, a->H, a->S, a->head_dim, "ovla_attn_bwd")) return rc;
+  OVLA_REQUIRE(stride_ok(a->q_stride) && stride_ok(a->k_stride) && stride_ok(a->v_stride) && stride_ok(a->o_stride) && stride_ok(a->do_stride) &&
+                   (a->dq_stride % 4) == 0 && (a->dk_stride % 4) == 0 && (a->dv_stride % 4) == 0,
+               "ovla_attn_bwd: row strides must be multiples of 8 elements");
+  OVLA_REQUIRE(aligned16(a->Q) && aligned16(a->K) && aligned16(a->V) && aligned16(a->O) && aligned16(a->dO), "ovla_attn_bwd: alignment");
+  AttnParams p = {};
+  p.Q = (const bf16_bits*)a->Q; p.K = (const bf16_bits*)a->K; p.V = (const bf16_bits*)a->V; p.O = (const bf16_bits*)a->O;
+  p.dO = (const bf16_bits*)a->dO; p.dQ = (bf16_bits*)a->dQ; p.dK = (bf16_bits*)a->dK; p.dV = (bf16_bits*)a->dV;
+  p.q_stride = a->q_stride; p.k_stride = a->k_stride; p.v_stride = a->v_stride; p.o_stride = a->o_stride; p.do_stride = a->do_stride;
+  p.dq_stride = a->dq_stride; p.dk_stride = a->dk_stride; p.dv_stride = a->dv_stride;
+  p.lse_in = a->lse; p.delta = a->delta; p.kv_len = a->kv_len;
+  p.B = a->B; p.H = a->H; p.S = a->S; p.hd = a->head_dim; p.causal = a->causal; p.scale = a->scale;
+  const int64_t items = (int64_t)a->B * a->S * a->H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(items, 16)), dim3(256), 0, stream, p);
+  OVLA_CHECK_LAUNCH("ovla_attn_bwd(delta)");
+  const dim3 grid(cdiv(a->S, BQ), a->H, a->B);
+  switch (a->head_dim) {
+    case 64:
+      hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(256), 0, stream, p);
+      break;
+    case 72:
+      hipLaunchKernelGGL(attn_bwd_dq_kernel<96>, grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL(attn_bwd_dkv_kernel<96>, grid, dim3(256), 0, stream, p);
+      break;
+    default:
+      hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(256), 0, stream, p);
+      break;
+  }
+  OVLA_CHECK_LAUNCH("ovla_attn_bwd");
+  return OVLA_OK;
+}

@@ -1,0 +1,644 @@
+// elementwise.hip -- HBM-bound kernels of the OpenVLA-OFT path: normalisation, RoPE, SwiGLU, activation backward,
+// multimodal assembly, row gathers, ViT embedding glue, casts/transposes.  All loads/stores are 8- or 16-byte vectors
+// of bf16 (cdna_hip_programming.md Guideline 13); reductions are wave shuffles + one LDS hop.
+#include "common.h"
+
+namespace {
+
+OVLA_DEV float block_sum_256(float v, float* red /* >= 4 floats */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+OVLA_DEV void load8(const bf16_bits* p, float (&f)[8]) {
+  const bf16x8_bits v = *reinterpret_cast<const bf16x8_bits*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = bf2f((bf16_bits)v[j]);
+}
+OVLA_DEV void store8(bf16_bits* p, const float (&f)[8]) {
+  bf16x8_bits v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (short)f2bf(f[j]);
+  *reinterpret_cast<bf16x8_bits*>(p) = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Norm forward: one 256-thread workgroup per row; the row is re-read from L2 for the second/third pass.
+// RMS (transformers LlamaRMSNorm): y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps)))
+// LN  (torch layer_norm, fp32 math): y = bf16((x - mean) * rstd * w + b)
+__global__ __launch_bounds__(256) void norm_fwd_kernel(const bf16_bits* __restrict__ x, bf16_bits* __restrict__ y,
+                                                       const bf16_bits* __restrict__ w, const bf16_bits* __restrict__ b,
+                                                       float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                       int dim, float eps, int is_rms) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const bf16_bits* xr = x + row * dim;
+  bf16_bits* yr = y + row * dim;
+  const int nchunk = dim >> 3;
+  float s = 0.f;
+  float mean = 0.f;
+  if (!is_rms) {
+    for (int c = threadIdx.x; c < nchunk; c += 256) {
+      float f[8];
+      load8(xr + c * 8, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += f[j];
+    }
+    mean = block_sum_256(s, red) / (float)dim;
+  }
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
+    float f[8];
+    load8(xr + c * 8, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = f[j] - mean;
+      ss += d * d;
+    }
+  }
+  const float var = block_sum_256(ss, red) / (float)dim;
+  const float rstd = rsqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    if (mean_out) mean_out[row] = mean;
+    if (rstd_out) rstd_out[row] = rstd;
+  }
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
+    float f[8], wf[8], o[8];
+    load8(xr + c * 8, f);
+    load8(w + c * 8, wf);
+    if (is_rms) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = wf[j] * bfround(f[j] * rstd);
+    } else {
+      float bfv[8];
+      if (b) load8(b + c * 8, bfv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (f[j] - mean) * rstd * wf[j] + (b ? bfv[j] : 0.f);
+    }
+    store8(yr + c * 8, o);
+  }
+}
+
+// Norm backward: g = dy * w; xhat = (x - mean) * rstd
+//   RMS: dx = rstd * (g - xhat * mean(g * xhat));   LN: dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
+__global__ __launch_bounds__(256) void norm_bwd_kernel(const bf16_bits* __restrict__ x, const bf16_bits* __restrict__ dy,
+                                                       const bf16_bits* __restrict__ w, const float* __restrict__ mean_in,
+                                                       const float* __restrict__ rstd_in, bf16_bits* __restrict__ dx,
+                                                       float* __restrict__ dw, float* __restrict__ db, int dim, int is_rms,
+                                                       int dx_accum) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const bf16_bits* xr = x + row * dim;
+  const bf16_bits* dyr = dy + row * dim;
+  bf16_bits* dxr = dx + row * dim;
+  const float mean = is_rms ? 0.f : mean_in[row];
+  const float rstd = rstd_in[row];
+  const int nchunk = dim >> 3;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
+    float f[8], g[8], wf[8];
+    load8(xr + c * 8, f);
+    load8(dyr + c * 8, g);
+    load8(w + c * 8, wf);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gj = g[j] * wf[j];
+      s1 += gj;
+      s2 += gj * (f[j] - mean) * rstd;
+    }
+  }
+  const float m1 = is_rms ? 0.f : block_sum_256(s1, red) / (float)dim;
+  const float m2 = block_sum_256(s2, red) / (float)dim;
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
+    float f[8], g[8], wf[8], o[8];
+    load8(xr + c * 8, f);
+    load8(dyr + c * 8, g);
+    load8(w + c * 8, wf);
+    if (dx_accum) load8(dxr + c * 8, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xhat = (f[j] - mean) * rstd;
+      const float v = rstd * (g[j] * wf[j] - m1 - xhat * m2);
+      o[j] = dx_accum ? o[j] + v : v;
+      if (dw) atomicAdd(dw + c * 8 + j, g[j] * xhat);
+      if (db) atomicAdd(db + c * 8 + j, g[j]);
+    }
+    store8(dxr + c * 8, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RoPE tables and in-place rotation.  HF convention: cos/sin are fp32, cast to bf16; q' = bf16(bf16(q*c) + bf16(rot(q)*s)).
+__global__ void rope_table_kernel(bf16_bits* cosT, bf16_bits* sinT, int S, int half, float theta) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= S * half) return;
+  const int pos = idx / half, i = idx % half;
+  const float inv_freq = 1.0f / powf(theta, (float)(2 * i) / (float)(2 * half));
+  const float ang = (float)pos * inv_freq;
+  cosT[idx] = f2bf(cosf(ang));
+  sinT[idx] = f2bf(sinf(ang));
+}
+
+__global__ __launch_bounds__(256) void rope_kernel(bf16_bits* __restrict__ qk, int64_t ld, int rows, int S, int n_heads,
+                                                   int head_dim, const bf16_bits* __restrict__ cosT,
+                                                   const bf16_bits* __restrict__ sinT, int inverse) {
+  const int half = head_dim >> 1;
+  const int cpr = half >> 2;  // 4-element chunks per half head
+  const int64_t total = (int64_t)rows * n_heads * cpr;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cpr);
+    const int h = (int)((idx / cpr) % n_heads);
+    const int64_t row = idx / ((int64_t)cpr * n_heads);
+    const int pos = (int)(row % S);
+    bf16_bits* base = qk + row * ld + (int64_t)h * head_dim + c * 4;
+    const bf16x4_bits lo = *reinterpret_cast<const bf16x4_bits*>(base);
+    const bf16x4_bits hi = *reinterpret_cast<const bf16x4_bits*>(base + half);
+    const bf16x4_bits cs = *reinterpret_cast<const bf16x4_bits*>(cosT + (int64_t)pos * half + c * 4);
+    const bf16x4_bits sn = *reinterpret_cast<const bf16x4_bits*>(sinT + (int64_t)pos * half + c * 4);
+    bf16x4_bits olo, ohi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = bf2f((bf16_bits)lo[j]), b = bf2f((bf16_bits)hi[j]);
+      const float cc = bf2f((bf16_bits)cs[j]);
+      const float s = inverse ? -bf2f((bf16_bits)sn[j]) : bf2f((bf16_bits)sn[j]);
+      // forward: lo' = a*c - b*s ; hi' = b*c + a*s     (rotate_half(x) = [-x_hi, x_lo])
+      olo[j] = (short)f2bf(bfround(a * cc) + bfround(-b * s));
+      ohi[j] = (short)f2bf(bfround(b * cc) + bfround(a * s));
+    }
+    *reinterpret_cast<bf16x4_bits*>(base) = olo;
+    *reinterpret_cast<bf16x4_bits*>(base + half) = ohi;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_bits* __restrict__ gu, bf16_bits* __restrict__ h,
+                                                         int rows, int F) {
+  const int cpr = F >> 3;
+  const int64_t total = (int64_t)rows * cpr;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / cpr;
+    const int c = (int)(idx % cpr);
+    float g[8], u[8], o[8];
+    load8(gu + row * 2 * F + c * 8, g);
+    load8(gu + row * 2 * F + F + c * 8, u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = bfround(silu(g[j])) * u[j];
+    store8(h + row * F + c * 8, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_bits* __restrict__ gu, const bf16_bits* __restrict__ dh,
+                                                         bf16_bits* __restrict__ dgu, int rows, int F) {
+  const int cpr = F >> 3;
+  const int64_t total = (int64_t)rows * cpr;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / cpr;
+    const int c = (int)(idx % cpr);
+    float g[8], u[8], d[8], dg[8], du[8];
+    load8(gu + row * 2 * F + c * 8, g);
+    load8(gu + row * 2 * F + F + c * 8, u);
+    load8(dh + row * F + c * 8, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float s = sigmoidf_(g[j]);
+      const float sl = g[j] * s;
+      du[j] = d[j] * bfround(sl);
+      dg[j] = d[j] * u[j] * (s * (1.f + g[j] * (1.f - s)));
+    }
+    store8(dgu + row * 2 * F + c * 8, dg);
+    store8(dgu + row * 2 * F + F + c * 8, du);
+  }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_bits* __restrict__ z, const bf16_bits* __restrict__ dh,
+                                                      bf16_bits* __restrict__ dz, int64_t nchunk, int act) {
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += (int64_t)gridDim.x * blockDim.x) {
+    float zf[8], d[8], o[8];
+    load8(z + c * 8, zf);
+    load8(dh + c * 8, d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = d[j] * act_grad(zf[j], act);
+    store8(dz + c * 8, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const bf16_bits* __restrict__ a, const bf16_bits* __restrict__ b,
+                                                  bf16_bits* __restrict__ out, int64_t nchunk) {
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += (int64_t)gridDim.x * blockDim.x) {
+    float x[8], y[8];
+    load8(a + c * 8, x);
+    if (b) {
+      load8(b + c * 8, y);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] += y[j];
+    }
+    store8(out + c * 8, x);
+  }
+}
+
+__global__ __launch_bounds__(256) void colscale_kernel(const bf16_bits* __restrict__ x, const bf16_bits* __restrict__ s,
+                                                       bf16_bits* __restrict__ out, int rows, int dim) {
+  const int cpr = dim >> 3;
+  const int64_t total = (int64_t)rows * cpr;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cpr);
+    float f[8], sf[8];
+    load8(x + idx * 8, f);
+    load8(s + c * 8, sf);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] *= sf[j];
+    store8(out + idx * 8, f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// im2col for patch embedding: out[(b, gy, gx), (c, py, px)], K padded with zeros up to ldo.
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16_bits* __restrict__ px, bf16_bits* __restrict__ out, int64_t ldo,
+                                                     int B, int C_total, int c0, int H, int W, int patch) {
+  const int gh = H / patch, gw = W / patch;
+  const int64_t total = (int64_t)B * gh * gw * ldo;
+  const int kreal = 3 * patch * patch;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % ldo);
+    const int64_t r = idx / ldo;
+    bf16_bits v = 0;
+    if (k < kreal) {
+      const int c = k / (patch * patch), py = (k / patch) % patch, pxx = k % patch;
+      const int gx = (int)(r % gw), gy = (int)((r / gw) % gh);
+      const int64_t b = r / ((int64_t)gw * gh);
+      v = px[((b * C_total + c0 + c) * H + gy * patch + py) * (int64_t)W + gx * patch + pxx];
+    }
+    out[idx] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void vit_embed_kernel(const bf16_bits* __restrict__ patches, const bf16_bits* __restrict__ pos,
+                                                        const bf16_bits* __restrict__ prefix, bf16_bits* __restrict__ tokens,
+                                                        int B, int n_patches, int n_prefix, int dim) {
+  const int cpr = dim >> 3;
+  const int ntok = n_patches + n_prefix;
+  const int64_t total = (int64_t)B * ntok * cpr;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cpr);
+    const int t = (int)((idx / cpr) % ntok);
+    const int64_t b = idx / ((int64_t)cpr * ntok);
+    float f[8];
+    if (t < n_prefix) {
+      load8(prefix + (int64_t)t * dim + c * 8, f);
+    } else {
+      float pf[8];
+      load8(patches + ((b * n_patches) + (t - n_prefix)) * (int64_t)dim + c * 8, f);
+      load8(pos + (int64_t)(t - n_prefix) * dim + c * 8, pf);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] += pf[j];
+    }
+    store8(tokens + idx * 8, f);
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_bits* __restrict__ src, bf16_bits* __restrict__ dst, int B,
+                                                        int rows, int dim, int64_t sbs, int64_t sr0, int64_t sld, int64_t dbs,
+                                                        int64_t dr0, int64_t dld, int64_t dc0, int accumulate) {
+  const int cpr = dim >> 3;
+  const int64_t total = (int64_t)B * rows * cpr;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cpr);
+    const int r = (int)((idx / cpr) % rows);
+    const int64_t b = idx / ((int64_t)cpr * rows);
+    float f[8];
+    load8(src + b * sbs + (sr0 + r) * sld + c * 8, f);
+    bf16_bits* d = dst + b * dbs + (dr0 + r) * dld + dc0 + c * 8;
+    if (accumulate) {
+      float g[8];
+      load8(d, g);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] += g[j];
+    }
+    store8(d, f);
+  }
+}
+
+// out[b, :] = mean over rows i with row_mask[b,i] != 0 of x[b, i, :]   (FiLM average language embedding)
+__global__ __launch_bounds__(256) void masked_mean_kernel(const bf16_bits* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                          bf16_bits* __restrict__ out, int B, int L, int dim) {
+  const int b = blockIdx.y;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= dim) return;
+  float s = 0.f;
+  int cnt = 0;
+  for (int i = 0; i < L; ++i) {
+    if (mask[(int64_t)b * L + i]) {
+      s += bf2f(x[((int64_t)b * L + i) * dim + col]);
+      ++cnt;
+    }
+  }
+  out[(int64_t)b * dim + col] = f2bf(s / (float)(cnt > 0 ? cnt : 1));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multimodal assembly.  One workgroup per output row (b, s).  The action mask follows train_utils.py:8-39 exactly:
+// cumsum(labels != IGNORE) >= 1 and labels > ACTION_TOKEN_BEGIN_IDX.
+__global__ __launch_bounds__(256) void assemble_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ labels,
+                                                       const bf16_bits* __restrict__ table, const bf16_bits* __restrict__ patches,
+                                                       const bf16_bits* __restrict__ noisy, bf16_bits* __restrict__ out,
+                                                       int32_t* __restrict__ action_pos, int B, int L, int P, int D, int A,
+                                                       int vocab, int ignore_index, int action_begin) {
+  __shared__ int sh_is_action, sh_slot;
+  const int S = P + L;
+  const int b = blockIdx.x / S, s = blockIdx.x % S;
+  bf16_bits* o = out + ((int64_t)b * S + s) * D;
+  const bf16_bits* src = nullptr;
+  bool zero = false;
+  if (s >= 1 && s <= P) {
+    src = patches + ((int64_t)b * P + (s - 1)) * D;
+  } else {
+    const int i = (s == 0) ? 0 : s - P;  // text index
+    if (threadIdx.x == 0) {
+      const int64_t* lab = labels + (int64_t)b * L;
+      int cum = 0, slot = 0, is_action = 0;
+      for (int j = 0; j <= i; ++j) {
+        cum += (lab[j] != ignore_index) ? 1 : 0;
+        const int act = (cum >= 1 && lab[j] > action_begin) ? 1 : 0;
+        if (j < i) slot += act; else is_action = act;
+      }
+      sh_is_action = is_action;
+      sh_slot = slot;
+      if (is_action && action_pos && slot < A) action_pos[(int64_t)b * A + slot] = i;
+    }
+    __syncthreads();
+    if (sh_is_action) {
+      if (noisy && sh_slot < A) src = noisy + ((int64_t)b * A + sh_slot) * D;
+      else zero = true;
+    } else {
+      int64_t id = ids[(int64_t)b * L + i];
+      if (id < 0) id = 0;
+      if (id >= vocab) id = vocab - 1;
+      src = table + id * D;
+    }
+  }
+  for (int c = threadIdx.x; c < (D >> 3); c += 256) {
+    bf16x8_bits v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!zero) v = *reinterpret_cast<const bf16x8_bits*>(src + c * 8);
+    *reinterpret_cast<bf16x8_bits*>(o + c * 8) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_bits* __restrict__ src, const int32_t* __restrict__ index,
+                                                          bf16_bits* __restrict__ dst, int n, int dim, int64_t src_ld,
+                                                          int64_t dst_ld, int scatter_add) {
+  const int i = blockIdx.x;
+  const int64_t r = index[i];
+  for (int c = threadIdx.x; c < (dim >> 3); c += 256) {
+    if (!scatter_add) {
+      *reinterpret_cast<bf16x8_bits*>(dst + (int64_t)i * dst_ld + c * 8) =
+          *reinterpret_cast<const bf16x8_bits*>(src + r * src_ld + c * 8);
+    } else {  // dst[index[i]] += src[i]   (indices are unique per launch on this path)
+      float a[8], bb[8];
+      load8(src + (int64_t)i * src_ld + c * 8, a);
+      load8(dst + r * dst_ld + c * 8, bb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += bb[j];
+      store8(dst + r * dst_ld + c * 8, a);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cvt_f32_bf16_kernel(const float* __restrict__ src, bf16_bits* __restrict__ dst, int64_t n,
+                                                           float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = f2bf(src[i] * scale);
+}
+__global__ __launch_bounds__(256) void cvt_bf16_f32_kernel(const bf16_bits* __restrict__ src, float* __restrict__ dst, int64_t n,
+                                                           float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = bf2f(src[i]) * scale;
+}
+
+// 64x64 tile transpose through LDS (padded rows: no bank conflicts)
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_bits* __restrict__ src, bf16_bits* __restrict__ dst, int rows,
+                                                        int cols, int64_t lds_, int64_t ldd) {
+  __shared__ bf16_bits tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(int64_t)(r0 + r) * lds_ + c0 + c] : (bf16_bits)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < rows && c0 + c < cols) dst[(int64_t)(c0 + c) * ldd + r0 + r] = tile[r][c];
+  }
+}
+
+// column sums: out[n] += sum_m X[m,n]; grid (N/64 col blocks, row chunks)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_bits* __restrict__ X, int64_t ldx, float* __restrict__ out, int M,
+                                                     int N, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = (r0 + rows_per_block) < M ? (r0 + rows_per_block) : M;
+  float s = 0.f;
+  if (col < N)
+    for (int r = r0 + sub; r < r1; r += 4) s += bf2f(X[(int64_t)r * ldx + col]);
+  red[sub][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sub == 0 && col < N) atomicAdd(out + col, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+inline int grid_for(int64_t work_items) {
+  int64_t b = (work_items + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int ovla_norm_fwd(const ovla_norm_fwd_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->x && a->y && a->weight, "ovla_norm_fwd: null pointer");
+  OVLA_REQUIRE(a->rows > 0 && a->dim > 0 && (a->dim % 8) == 0, "ovla_norm_fwd: rows=%d dim=%d (dim %% 8 == 0)", a->rows, a->dim);
+  OVLA_REQUIRE(aligned16(a->x) && aligned16(a->y) && aligned16(a->weight) && (!a->bias || aligned16(a->bias)), "ovla_norm_fwd: 16-byte alignment");
+  hipLaunchKernelGGL(norm_fwd_kernel, dim3(a->rows), dim3(256), 0, stream, (const bf16_bits*)a->x, (bf16_bits*)a->y,
+                     (const bf16_bits*)a->weight, (const bf16_bits*)a->bias, a->mean, a->rstd, a->dim, a->eps, a->is_rms);
+  OVLA_CHECK_LAUNCH("ovla_norm_fwd");
+  return OVLA_OK;
+}
+
+extern "C" int ovla_norm_bwd(const ovla_norm_bwd_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->x && a->dy && a->weight && a->rstd && a->dx, "ovla_norm_bwd: null pointer");
+  OVLA_REQUIRE(a->is_rms || a->mean, "ovla_norm_bwd: LayerNorm needs mean");
+  OVLA_REQUIRE(a->rows > 0 && a->dim > 0 && (a->dim % 8) == 0, "ovla_norm_bwd: rows=%d dim=%d", a->rows, a->dim);
+  OVLA_REQUIRE(aligned16(a->x) && aligned16(a->dy) && aligned16(a->dx) && aligned16(a->weight), "ovla_norm_bwd: 16-byte alignment");
+  hipLaunchKernelGGL(norm_bwd_kernel, dim3(a->rows), dim3(256), 0, stream, (const bf16_bits*)a->x, (const bf16_bits*)a->dy,
+                     (const bf16_bits*)a->weight, a->mean, a->rstd, (bf16_bits*)a->dx, a->dweight, a->dbias, a->dim, a->is_rms,
+                     a->dx_accum);
+  OVLA_CHECK_LAUNCH("ovla_norm_bwd");
+  return OVLA_OK;
+}
+
+extern "C" int ovla_rope_table(void* cos_table, void* sin_table, int32_t S, int32_t head_dim, float theta, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(cos_table && sin_table && S > 0 && head_dim > 0 && (head_dim % 8) == 0, "ovla_rope_table: bad arguments");
+  const int half = head_dim / 2;
+  hipLaunchKernelGGL(rope_table_kernel, dim3(cdiv((int64_t)S * half, 256)), dim3(256), 0, stream, (bf16_bits*)cos_table,
+                     (bf16_bits*)sin_table, S, half, theta);
+  OVLA_CHECK_LAUNCH("ovla_rope_table");
+  return OVLA_OK;
+}
+
+extern "C" int ovla_rope(const ovla_rope_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->qk && a->cos_table && a->sin_table, "ovla_rope: null pointer");
+  OVLA_REQUIRE(a->rows > 0 && a->S > 0 && a->n_heads > 0 && (a->head_dim % 8) == 0 && (a->ld % 4) == 0, "ovla_rope: bad shape");
+  OVLA_REQUIRE((((uintptr_t)a->qk) & 7) == 0, "ovla_rope: qk must be 8-byte aligned");
+  const int64_t work = (int64_t)a->rows * a->n_heads * (a->head_dim / 8);
+  hipLaunchKernelGGL(rope_kernel, dim3(grid_for(work)), dim3(256), 0, stream, (bf16_bits*)a->qk, a->ld, a->rows, a->S, a->n_heads,
+                     a->head_dim, (const bf16_bits*)a->cos_table, (const bf16_bits*)a->sin_table, a->inverse);
+  OVLA_CHECK_LAUNCH("ovla_rope");
+  return OVLA_OK;
+}
+
+extern "C" int ovla_swiglu_fwd(const ovla_swiglu_fwd_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->gu && a->h && a->rows > 0 && a->F > 0 && (a->F % 8) == 0, "ovla_swiglu_fwd: bad arguments");
+  OVLA_REQUIRE(aligned16(a->gu) && aligned16(a->h), "ovla_swiglu_fwd: 16-byte alignment");
+  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for((int64_t)a->rows * a->F / 8)), dim3(256), 0, stream, (const bf16_bits*)a->gu,
+                     (bf16_bits*)a->h, a->rows, a->F);
+  OVLA_CHECK_LAUNCH("ovla_swiglu_fwd");
+  return OVLA_OK;
+}
+extern "C" int ovla_swiglu_bwd(const ovla_swiglu_bwd_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->gu && a->dh && a->dgu && a->rows > 0 && a->F > 0 && (a->F % 8) == 0, "ovla_swiglu_bwd: bad arguments");
+  OVLA_REQUIRE(aligned16(a->gu) && aligned16(a->dh) && aligned16(a->dgu), "ovla_swiglu_bwd: 16-byte alignment");
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((int64_t)a->rows * a->F / 8)), dim3(256), 0, stream, (const bf16_bits*)a->gu,
+                     (const bf16_bits*)a->dh, (bf16_bits*)a->dgu, a->rows, a->F);
+  OVLA_CHECK_LAUNCH("ovla_swiglu_bwd");
+  return OVLA_OK;
+}
+extern "C" int ovla_act_bwd(const ovla_act_bwd_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->z && a->dh && a->dz && a->n > 0 && (a->n % 8) == 0, "ovla_act_bwd: bad arguments");
+  OVLA_REQUIRE(aligned16(a->z) && aligned16(a->dh) && aligned16(a->dz), "ovla_act_bwd: 16-byte alignment");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(a->n / 8)), dim3(256), 0, stream, (const bf16_bits*)a->z, (const bf16_bits*)a->dh,
+                     (bf16_bits*)a->dz, a->n / 8, a->act);
+  OVLA_CHECK_LAUNCH("ovla_act_bwd");
+  return OVLA_OK;
+}
+extern "C" int ovla_add_bf16(const ovla_add_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->a && a->out && a->n > 0 && (a->n % 8) == 0, "ovla_add_bf16: bad arguments");
+  OVLA_REQUIRE(aligned16(a->a) && aligned16(a->out) && (!a->b || aligned16(a->b)), "ovla_add_bf16: 16-byte alignment");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(a->n / 8)), dim3(256), 0, stream, (const bf16_bits*)a->a, (const bf16_bits*)a->b,
+                     (bf16_bits*)a->out, a->n / 8);
+  OVLA_CHECK_LAUNCH("ovla_add_bf16");
+  return OVLA_OK;
+}
+extern "C" int ovla_colscale_bf16(const ovla_colscale_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->x && a->scale && a->out && a->rows > 0 && a->dim > 0 && (a->dim % 8) == 0, "ovla_colscale_bf16: bad arguments");
+  hipLaunchKernelGGL(colscale_kernel, dim3(grid_for((int64_t)a->rows * a->dim / 8)), dim3(256), 0, stream, (const bf16_bits*)a->x,
+                     (const bf16_bits*)a->scale, (bf16_bits*)a->out, a->rows, a->dim);
+  OVLA_CHECK_LAUNCH("ovla_colscale_bf16");
+  return OVLA_OK;
+}
+extern "C" int ovla_im2col(const ovla_im2col_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->pixels && a->out, "ovla_im2col: null pointer");
+  OVLA_REQUIRE(a->B > 0 && a->patch > 0 && a->H % a->patch == 0 && a->W % a->patch == 0, "ovla_im2col: image %dx%d not divisible by patch %d", a->H, a->W, a->patch);
+  OVLA_REQUIRE(a->c0 >= 0 && a->c0 + 3 <= a->C_total && a->ldo >= 3 * a->patch * a->patch, "ovla_im2col: channel range / ldo");
+  const int64_t total = (int64_t)a->B * (a->H / a->patch) * (a->W / a->patch) * a->ldo;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_bits*)a->pixels, (bf16_bits*)a->out, a->ldo,
+                     a->B, a->C_total, a->c0, a->H, a->W, a->patch);
+  OVLA_CHECK_LAUNCH("ovla_im2col");
+  return OVLA_OK;
+}
+extern "C" int ovla_vit_embed(const ovla_vit_embed_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->patches && a->pos && a->tokens && (a->n_prefix == 0 || a->prefix), "ovla_vit_embed: null pointer");
+  OVLA_REQUIRE(a->B > 0 && a->n_patches > 0 && (a->dim % 8) == 0, "ovla_vit_embed: bad shape");
+  const int64_t total = (int64_t)a->B * (a->n_patches + a->n_prefix) * (a->dim / 8);
+  hipLaunchKernelGGL(vit_embed_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_bits*)a->patches, (const bf16_bits*)a->pos,
+                     (const bf16_bits*)a->prefix, (bf16_bits*)a->tokens, a->B, a->n_patches, a->n_prefix, a->dim);
+  OVLA_CHECK_LAUNCH("ovla_vit_embed");
+  return OVLA_OK;
+}
+extern "C" int ovla_copy_rows(const ovla_copy_rows_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->src && a->dst && a->B > 0 && a->rows > 0 && a->dim > 0 && (a->dim % 8) == 0, "ovla_copy_rows: bad arguments");
+  OVLA_REQUIRE((a->src_ld % 8) == 0 && (a->dst_ld % 8) == 0 && (a->dst_col0 % 8) == 0 && (a->src_batch_stride % 8) == 0 && (a->dst_batch_stride % 8) == 0,
+               "ovla_copy_rows: strides must be multiples of 8 elements");
+  OVLA_REQUIRE(aligned16(a->src) && aligned16(a->dst), "ovla_copy_rows: 16-byte alignment");
+  const int64_t total = (int64_t)a->B * a->rows * (a->dim / 8);
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_bits*)a->src, (bf16_bits*)a->dst, a->B,
+                     a->rows, a->dim, a->src_batch_stride, a->src_row0, a->src_ld, a->dst_batch_stride, a->dst_row0, a->dst_ld,
+                     a->dst_col0, a->accumulate);
+  OVLA_CHECK_LAUNCH("ovla_copy_rows");
+  return OVLA_OK;
+}
+extern "C" int ovla_masked_mean(const ovla_masked_mean_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->x && a->row_mask && a->out && a->B > 0 && a->L > 0 && a->dim > 0, "ovla_masked_mean: bad arguments");
+  hipLaunchKernelGGL(masked_mean_kernel, dim3(cdiv(a->dim, 256), a->B), dim3(256), 0, stream, (const bf16_bits*)a->x, a->row_mask,
+                     (bf16_bits*)a->out, a->B, a->L, a->dim);
+  OVLA_CHECK_LAUNCH("ovla_masked_mean");
+  return OVLA_OK;
+}
+extern "C" int ovla_assemble_multimodal(const ovla_assemble_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->ids && a->labels && a->embed_table && a->patches && a->out, "ovla_assemble_multimodal: null pointer");
+  OVLA_REQUIRE(a->B > 0 && a->L > 0 && a->P > 0 && a->D > 0 && (a->D % 8) == 0 && a->vocab > 0, "ovla_assemble_multimodal: bad shape");
+  OVLA_REQUIRE(aligned16(a->embed_table) && aligned16(a->patches) && aligned16(a->out), "ovla_assemble_multimodal: 16-byte alignment");
+  hipLaunchKernelGGL(assemble_kernel, dim3(a->B * (a->P + a->L)), dim3(256), 0, stream, a->ids, a->labels, (const bf16_bits*)a->embed_table,
+                     (const bf16_bits*)a->patches, (const bf16_bits*)a->noisy, (bf16_bits*)a->out, a->action_pos, a->B, a->L, a->P, a->D,
+                     a->A, a->vocab, a->ignore_index, a->action_token_begin);
+  OVLA_CHECK_LAUNCH("ovla_assemble_multimodal");
+  return OVLA_OK;
+}
+extern "C" int ovla_gather_rows(const ovla_gather_rows_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->src && a->index && a->dst && a->n > 0 && a->dim > 0 && (a->dim % 8) == 0, "ovla_gather_rows: bad arguments");
+  OVLA_REQUIRE((a->src_ld % 8) == 0 && (a->dst_ld % 8) == 0 && aligned16(a->src) && aligned16(a->dst), "ovla_gather_rows: alignment");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(a->n), dim3(256), 0, stream, (const bf16_bits*)a->src, a->index, (bf16_bits*)a->dst, a->n,
+                     a->dim, a->src_ld, a->dst_ld, a->scatter_add);
+  OVLA_CHECK_LAUNCH("ovla_gather_rows");
+  return OVLA_OK;
+}
+extern "C" int ovla_cvt_f32_to_bf16(const ovla_cvt_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->src && a->dst && a->n > 0, "ovla_cvt_f32_to_bf16: bad arguments");
+  hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3(grid_for(a->n)), dim3(256), 0, stream, a->src, (bf16_bits*)a->dst, a->n, a->scale);
+  OVLA_CHECK_LAUNCH("ovla_cvt_f32_to_bf16");
+  return OVLA_OK;
+}
+extern "C" int ovla_cvt_bf16_to_f32(const void* src, float* dst, int64_t n, float scale, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(src && dst && n > 0, "ovla_cvt_bf16_to_f32: bad arguments");
+  hipLaunchKernelGGL(cvt_bf16_f32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const bf16_bits*)src, dst, n, scale);
+  OVLA_CHECK_LAUNCH("ovla_cvt_bf16_to_f32");
+  return OVLA_OK;
+}
+extern "C" int ovla_transpose_bf16(const ovla_transpose_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->src && a->dst && a->rows > 0 && a->cols > 0 && a->lds >= a->cols && a->ldd >= a->rows, "ovla_transpose_bf16: bad arguments");
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(a->cols, 64), cdiv(a->rows, 64)), dim3(256), 0, stream, (const bf16_bits*)a->src,
+                     (bf16_bits*)a->dst, a->rows, a->cols, a->lds, a->ldd);
+  OVLA_CHECK_LAUNCH("ovla_transpose_bf16");
+  return OVLA_OK;
+}
+extern "C" int ovla_colsum_bf16(const ovla_colsum_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->X && a->out && a->M > 0 && a->N > 0, "ovla_colsum_bf16: bad arguments");
+  const int rpb = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(a->N, 64), cdiv(a->M, rpb)), dim3(256), 0, stream, (const bf16_bits*)a->X, a->ldx, a->out,
+                     a->M, a->N, rpb);
+  OVLA_CHECK_LAUNCH("ovla_colsum_bf16");
+  return OVLA_OK;
+}

@@ -1,0 +1,379 @@
+"""Tensor-level wrappers over the C-ABI (include/ovla.h).  PyTorch is used here only as the owner of device memory
+and of the HIP stream; every arithmetic op below is a hand-written gfx950 kernel in libovla_hip.so.  Nothing in this
+module falls back to torch math: a missing library or a failed launch raises.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import STRUCTS
+
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU, ACT_GELU_TANH = 0, 1, 2, 3, 4
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype=BF16, name="tensor"):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
+
+
+def check_device(index: int = 0) -> None:
+    _lib.check(_lib.lib().ovla_check_device(index), "ovla_check_device")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=None, c_pre=None, a2=None, b2=None,
+         k2_group_n=0, film=None, split_k=1, tile=0):
+    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T (+ a2[M,G*K2] @ b2[N,K2]^T)); all bf16 2-D, last dim contiguous."""
+    _chk(a, name="a"); _chk(b, name="b")
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K, f"gemm: K mismatch {a.shape} x {b.shape}"
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    g = STRUCTS["ovla_gemm_args"]()
+    g.A, g.lda, g.B, g.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
+    g.C, g.ldc = out.data_ptr(), out.stride(0)
+    if a2 is not None:
+        assert b2 is not None and a2.stride(1) == 1 and b2.stride(1) == 1 and b2.shape[0] == N and a2.shape[0] == M
+        g.A2, g.lda2, g.B2, g.ldb2, g.K2 = a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), b2.shape[1]
+        g.k2_group_n = k2_group_n
+    if c_pre is not None:
+        assert c_pre.shape == (M, N) and c_pre.stride(0) == out.stride(0)
+        g.C_pre = c_pre.data_ptr()
+    if bias is not None:
+        assert bias.numel() == N
+        g.bias = bias.data_ptr()
+    if colscale is not None:
+        assert colscale.numel() == N
+        g.colscale = colscale.data_ptr()
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+        g.residual, g.ldr = residual.data_ptr(), residual.stride(0)
+    if film is not None:
+        gamma, beta, rows = film
+        assert gamma.shape[-1] == N and gamma.is_contiguous() and beta.is_contiguous()
+        g.film_gamma, g.film_beta, g.film_rows = gamma.data_ptr(), beta.data_ptr(), rows
+    g.M, g.N, g.K, g.act, g.split_k, g.tile = M, N, K, act, split_k, tile
+    ws = None
+    if split_k > 1:
+        ws = torch.empty((split_k, M, N), dtype=torch.float32, device=a.device)
+        g.workspace = ws.data_ptr()
+    _lib.call("ovla_gemm_bf16", g, _stream())
+    return out
+
+
+def gemm_tn(x, y, *, out=None, alpha=1.0, accumulate=True, out_dtype=torch.float32):
+    """out[P,Q] (+)= alpha * x[M,P]^T @ y[M,Q].  accumulate=True: fp32 atomic accumulation into `out`."""
+    _chk(x, name="x"); _chk(y, name="y")
+    M, P = x.shape
+    Q = y.shape[1]
+    assert y.shape[0] == M and x.stride(1) == 1 and y.stride(1) == 1
+    if out is None:
+        out = torch.zeros((P, Q), dtype=out_dtype, device=x.device) if accumulate else torch.empty((P, Q), dtype=out_dtype, device=x.device)
+    assert out.shape == (P, Q) and out.stride(1) == 1
+    g = STRUCTS["ovla_gemm_tn_args"]()
+    g.X, g.ldx, g.Y, g.ldy, g.C, g.ldc = x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), out.data_ptr(), out.stride(0)
+    g.M, g.P, g.Q, g.alpha = M, P, Q, alpha
+    if accumulate:
+        assert out.dtype == torch.float32
+        g.out_mode = 0
+    else:
+        g.out_mode = 1 if out.dtype == torch.float32 else 2
+    _lib.call("ovla_gemm_tn_bf16", g, _stream())
+    return out
+
+
+def colsum(x, out):
+    """out[n] += sum_m x[m,n]  (fp32 accumulate)."""
+    _chk(x); _chk(out, torch.float32)
+    g = STRUCTS["ovla_colsum_args"]()
+    g.X, g.ldx, g.out, g.M, g.N = x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], x.shape[1]
+    _lib.call("ovla_colsum_bf16", g, _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def attn_fwd(q, k, v, B, S, H, hd, *, kv_len=None, causal=False, scale=None, out=None):
+    """q/k/v: 2-D views [B*S, >=H*hd] (row stride arbitrary, heads contiguous).  Returns (out [B*S, H*hd], lse [B,H,S])."""
+    for t in (q, k, v):
+        _chk(t)
+        assert t.stride(1) == 1 and t.shape[0] == B * S
+    if out is None:
+        out = torch.empty((B * S, H * hd), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=q.device)
+    g = STRUCTS["ovla_attn_fwd_args"]()
+    g.Q, g.K, g.V, g.q_stride, g.k_stride, g.v_stride = q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), v.stride(0)
+    g.O, g.o_stride, g.lse, g.kv_len = out.data_ptr(), out.stride(0), lse.data_ptr(), _p(kv_len)
+    g.B, g.H, g.S, g.head_dim, g.causal = B, H, S, hd, int(causal)
+    g.scale = float(scale if scale is not None else hd ** -0.5)
+    _lib.call("ovla_attn_fwd", g, _stream())
+    return out, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, B, S, H, hd, *, kv_len=None, causal=False, scale=None, dq=None, dk=None, dv=None):
+    for t in (q, k, v, o, do):
+        _chk(t)
+        assert t.stride(1) == 1
+    dev = q.device
+    if dq is None:
+        dq = torch.empty((B * S, H * hd), dtype=BF16, device=dev)
+    if dk is None:
+        dk = torch.empty((B * S, H * hd), dtype=BF16, device=dev)
+    if dv is None:
+        dv = torch.empty((B * S, H * hd), dtype=BF16, device=dev)
+    delta = torch.empty((B, H, S), dtype=torch.float32, device=dev)
+    g = STRUCTS["ovla_attn_bwd_args"]()
+    g.Q, g.K, g.V, g.q_stride, g.k_stride, g.v_stride = q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), v.stride(0)
+    g.O, g.dO, g.o_stride, g.do_stride = o.data_ptr(), do.data_ptr(), o.stride(0), do.stride(0)
+    g.lse, g.delta = lse.data_ptr(), delta.data_ptr()
+    g.dQ, g.dK, g.dV, g.dq_stride, g.dk_stride, g.dv_stride = dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dq.stride(0), dk.stride(0), dv.stride(0)
+    g.kv_len = _p(kv_len)
+    g.B, g.H, g.S, g.head_dim, g.causal = B, H, S, hd, int(causal)
+    g.scale = float(scale if scale is not None else hd ** -0.5)
+    _lib.call("ovla_attn_bwd", g, _stream())
+    return dq, dk, dv
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def norm_fwd(x, weight, bias=None, *, eps, rms, out=None, save_stats=True):
+    _chk(x); _chk(weight)
+    rows, dim = x.shape
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if (save_stats and not rms) else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save_stats else None
+    g = STRUCTS["ovla_norm_fwd_args"]()
+    g.x, g.y, g.weight, g.bias, g.mean, g.rstd = x.data_ptr(), out.data_ptr(), weight.data_ptr(), _p(bias), _p(mean), _p(rstd)
+    g.rows, g.dim, g.eps, g.is_rms = rows, dim, eps, int(rms)
+    _lib.call("ovla_norm_fwd", g, _stream())
+    return out, mean, rstd
+
+
+def norm_bwd(x, dy, weight, mean, rstd, *, rms, dx=None, dx_accum=False, dweight=None, dbias=None):
+    _chk(x); _chk(dy)
+    rows, dim = x.shape
+    assert x.is_contiguous() and dy.is_contiguous()
+    if dx is None:
+        assert not dx_accum
+        dx = torch.empty_like(x)
+    g = STRUCTS["ovla_norm_bwd_args"]()
+    g.x, g.dy, g.weight, g.mean, g.rstd, g.dx = x.data_ptr(), dy.data_ptr(), weight.data_ptr(), _p(mean), rstd.data_ptr(), dx.data_ptr()
+    g.dweight, g.dbias, g.rows, g.dim, g.is_rms, g.dx_accum = _p(dweight), _p(dbias), rows, dim, int(rms), int(dx_accum)
+    _lib.call("ovla_norm_bwd", g, _stream())
+    return dx
+
+
+def rope_table(S, hd, theta, device):
+    cos = torch.empty((S, hd // 2), dtype=BF16, device=device)
+    sin = torch.empty((S, hd // 2), dtype=BF16, device=device)
+    _lib.check(_lib.lib().ovla_rope_table(cos.data_ptr(), sin.data_ptr(), S, hd, theta, _stream()), "ovla_rope_table")
+    return cos, sin
+
+
+def rope_(qk, S, n_heads, hd, cos, sin, inverse=False):
+    """In place on the first n_heads*hd columns of qk [rows, ld]."""
+    _chk(qk)
+    g = STRUCTS["ovla_rope_args"]()
+    g.qk, g.ld, g.rows, g.S, g.n_heads, g.head_dim = qk.data_ptr(), qk.stride(0), qk.shape[0], S, n_heads, hd
+    g.cos_table, g.sin_table, g.inverse = cos.data_ptr(), sin.data_ptr(), int(inverse)
+    _lib.call("ovla_rope", g, _stream())
+    return qk
+
+
+def swiglu_fwd(gu):
+    _chk(gu)
+    rows, F2 = gu.shape
+    h = torch.empty((rows, F2 // 2), dtype=BF16, device=gu.device)
+    g = STRUCTS["ovla_swiglu_fwd_args"]()
+    g.gu, g.h, g.rows, g.F = gu.data_ptr(), h.data_ptr(), rows, F2 // 2
+    _lib.call("ovla_swiglu_fwd", g, _stream())
+    return h
+
+
+def swiglu_bwd(gu, dh):
+    _chk(gu); _chk(dh)
+    rows, F2 = gu.shape
+    dgu = torch.empty_like(gu)
+    g = STRUCTS["ovla_swiglu_bwd_args"]()
+    g.gu, g.dh, g.dgu, g.rows, g.F = gu.data_ptr(), dh.data_ptr(), dgu.data_ptr(), rows, F2 // 2
+    _lib.call("ovla_swiglu_bwd", g, _stream())
+    return dgu
+
+
+def act_bwd(z, dh, act):
+    _chk(z); _chk(dh)
+    assert z.is_contiguous() and dh.is_contiguous()
+    dz = torch.empty_like(z)
+    g = STRUCTS["ovla_act_bwd_args"]()
+    g.z, g.dh, g.dz, g.n, g.act = z.data_ptr(), dh.data_ptr(), dz.data_ptr(), z.numel(), act
+    _lib.call("ovla_act_bwd", g, _stream())
+    return dz
+
+
+def add(a, b=None, out=None):
+    _chk(a)
+    if out is None:
+        out = torch.empty_like(a)
+    g = STRUCTS["ovla_add_args"]()
+    g.a, g.b, g.out, g.n = a.data_ptr(), _p(b), out.data_ptr(), a.numel()
+    _lib.call("ovla_add_bf16", g, _stream())
+    return out
+
+
+def colscale(x, scale, out=None):
+    _chk(x)
+    if out is None:
+        out = torch.empty_like(x)
+    g = STRUCTS["ovla_colscale_args"]()
+    g.x, g.scale, g.out, g.rows, g.dim = x.data_ptr(), scale.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1]
+    _lib.call("ovla_colscale_bf16", g, _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def im2col(pixels, c0, patch, k_padded):
+    _chk(pixels)
+    B, C, H, W = pixels.shape
+    assert pixels.is_contiguous()
+    out = torch.empty((B * (H // patch) * (W // patch), k_padded), dtype=BF16, device=pixels.device)
+    g = STRUCTS["ovla_im2col_args"]()
+    g.pixels, g.out, g.ldo, g.B, g.C_total, g.c0, g.H, g.W, g.patch = pixels.data_ptr(), out.data_ptr(), k_padded, B, C, c0, H, W, patch
+    _lib.call("ovla_im2col", g, _stream())
+    return out
+
+
+def vit_embed(patches, pos, prefix, B, n_patches, dim):
+    n_prefix = 0 if prefix is None else prefix.shape[0]
+    tokens = torch.empty((B * (n_patches + n_prefix), dim), dtype=BF16, device=patches.device)
+    g = STRUCTS["ovla_vit_embed_args"]()
+    g.patches, g.pos, g.prefix, g.tokens = patches.data_ptr(), pos.data_ptr(), _p(prefix), tokens.data_ptr()
+    g.B, g.n_patches, g.n_prefix, g.dim = B, n_patches, n_prefix, dim
+    _lib.call("ovla_vit_embed", g, _stream())
+    return tokens
+
+
+def copy_rows(src, dst, B, rows, dim, *, src_batch_stride, src_row0, src_ld, dst_batch_stride, dst_row0, dst_ld, dst_col0=0,
+              accumulate=False):
+    g = STRUCTS["ovla_copy_rows_args"]()
+    g.src, g.dst, g.B, g.rows, g.dim = src.data_ptr(), dst.data_ptr(), B, rows, dim
+    g.src_batch_stride, g.src_row0, g.src_ld = src_batch_stride, src_row0, src_ld
+    g.dst_batch_stride, g.dst_row0, g.dst_ld, g.dst_col0, g.accumulate = dst_batch_stride, dst_row0, dst_ld, dst_col0, int(accumulate)
+    _lib.call("ovla_copy_rows", g, _stream())
+    return dst
+
+
+def masked_mean(x, row_mask, B, L, dim):
+    out = torch.empty((B, dim), dtype=BF16, device=x.device)
+    g = STRUCTS["ovla_masked_mean_args"]()
+    g.x, g.row_mask, g.out, g.B, g.L, g.dim = x.data_ptr(), row_mask.data_ptr(), out.data_ptr(), B, L, dim
+    _lib.call("ovla_masked_mean", g, _stream())
+    return out
+
+
+def assemble_multimodal(ids, labels, table, patches, *, A, noisy=None, ignore_index=-100, action_token_begin=31743, action_dim=7):
+    """ids/labels int64 [B,L]; table bf16 [V,D]; patches bf16 [B,P,D] -> (out [B,P+L,D], action_pos int32 [B,A])."""
+    B, L = ids.shape
+    P, D = patches.shape[1], patches.shape[2]
+    out = torch.empty((B, P + L, D), dtype=BF16, device=table.device)
+    action_pos = torch.full((B, A), -1, dtype=torch.int32, device=table.device)
+    g = STRUCTS["ovla_assemble_args"]()
+    g.ids, g.labels, g.embed_table, g.patches, g.noisy = ids.data_ptr(), labels.data_ptr(), table.data_ptr(), patches.data_ptr(), _p(noisy)
+    g.out, g.action_pos = out.data_ptr(), action_pos.data_ptr()
+    g.B, g.L, g.P, g.D, g.A, g.vocab = B, L, P, D, A, table.shape[0]
+    g.ignore_index, g.action_token_begin, g.action_dim = ignore_index, action_token_begin, action_dim
+    _lib.call("ovla_assemble_multimodal", g, _stream())
+    return out, action_pos
+
+
+def gather_rows(src, index, dim, *, dst=None, scatter_add=False, n_dst_rows=None):
+    """gather: dst[i] = src[index[i]];  scatter_add: dst[index[i]] += src[i]."""
+    n = index.numel()
+    if dst is None:
+        dst = torch.empty((n, dim), dtype=BF16, device=src.device)
+    g = STRUCTS["ovla_gather_rows_args"]()
+    g.src, g.index, g.dst, g.n, g.dim = src.data_ptr(), index.data_ptr(), dst.data_ptr(), n, dim
+    g.src_ld, g.dst_ld, g.scatter_add = src.stride(0), dst.stride(0), int(scatter_add)
+    _lib.call("ovla_gather_rows", g, _stream())
+    return dst
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def head_out_fwd(x, W, b, target=None, loss_sum=None, mse=False):
+    rows, dim = x.shape
+    adim = W.shape[0]
+    pred = torch.empty((rows, adim), dtype=BF16, device=x.device)
+    g = STRUCTS["ovla_head_out_fwd_args"]()
+    g.x, g.W, g.b, g.pred, g.target, g.loss_sum = x.data_ptr(), W.data_ptr(), _p(b), pred.data_ptr(), _p(target), _p(loss_sum)
+    g.rows, g.dim, g.adim, g.mse = rows, dim, adim, int(mse)
+    _lib.call("ovla_head_out_fwd", g, _stream())
+    return pred
+
+
+def head_out_bwd(x, W, pred, target, dloss_scale, dW, db, mse=False):
+    rows, dim = x.shape
+    adim = W.shape[0]
+    dx = torch.empty_like(x)
+    g = STRUCTS["ovla_head_out_bwd_args"]()
+    g.x, g.W, g.pred, g.target, g.dloss_scale, g.mse = x.data_ptr(), W.data_ptr(), pred.data_ptr(), target.data_ptr(), dloss_scale, int(mse)
+    g.dx, g.dW, g.db, g.rows, g.dim, g.adim = dx.data_ptr(), _p(dW), _p(db), rows, dim, adim
+    _lib.call("ovla_head_out_bwd", g, _stream())
+    return dx
+
+
+def adamw(param, exp_avg, exp_avg_sq, grad, *, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0):
+    g = STRUCTS["ovla_adamw_args"]()
+    g.param, g.exp_avg, g.exp_avg_sq, g.grad = param.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), grad.data_ptr()
+    g.n, g.is_bf16, g.step = param.numel(), int(param.dtype == BF16), step
+    g.lr, g.beta1, g.beta2, g.eps, g.weight_decay, g.grad_scale = lr, beta1, beta2, eps, weight_decay, grad_scale
+    assert grad.dtype == torch.float32 and exp_avg.dtype == param.dtype and exp_avg_sq.dtype == param.dtype
+    _lib.call("ovla_adamw", g, _stream())
+
+
+def cvt_f32_to_bf16(src, dst=None, scale=1.0):
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=BF16, device=src.device)
+    g = STRUCTS["ovla_cvt_args"]()
+    g.src, g.dst, g.n, g.scale = src.data_ptr(), dst.data_ptr(), src.numel(), scale
+    _lib.call("ovla_cvt_f32_to_bf16", g, _stream())
+    return dst
+
+
+def cvt_bf16_to_f32(src, dst=None, scale=1.0):
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    _lib.check(_lib.lib().ovla_cvt_bf16_to_f32(src.data_ptr(), dst.data_ptr(), src.numel(), scale, _stream()), "ovla_cvt_bf16_to_f32")
+    return dst
+
+
+def transpose(src, dst=None):
+    _chk(src)
+    rows, cols = src.shape
+    assert src.stride(1) == 1
+    if dst is None:
+        dst = torch.empty((cols, rows), dtype=BF16, device=src.device)
+    g = STRUCTS["ovla_transpose_args"]()
+    g.src, g.dst, g.rows, g.cols, g.lds, g.ldd = src.data_ptr(), dst.data_ptr(), rows, cols, src.stride(0), dst.stride(0)
+    _lib.call("ovla_transpose_bf16", g, _stream())
+    return dst
+
+
+def selftest_layouts(device):
+    out = torch.zeros((4, 64, 16), dtype=torch.float32, device=device)
+    src = torch.arange(512, dtype=torch.float32, device=device).to(BF16)
+    _lib.check(_lib.lib().ovla_selftest_layouts(out.data_ptr(), src.data_ptr(), _stream()), "ovla_selftest_layouts")
+    return out

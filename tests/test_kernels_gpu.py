@@ -1,0 +1,443 @@
+"""Op-level parity of every HIP kernel (called through the C-ABI) against a plain PyTorch fp32 reference of the same op.
+
+Tolerances: outputs are bf16 (8 significant bits); a correctly rounded result differs from the fp32 reference by at most
+2^-8 relative, and accumulation-order effects add about one more ulp.  `close()` therefore checks
+max|out - ref| <= tol * max|ref| with tol stated per test (default 1.5e-2) plus a much tighter mean-error bound
+that catches layout bugs hidden under a loose max bound.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def close(out, ref, tol=1.5e-2, mean_tol=2.5e-3, what=""):
+    out, ref = out.float(), ref.float()
+    assert out.shape == ref.shape, f"{what}: shape {tuple(out.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    scale = ref.abs().max().item() + 1e-12
+    err = (out - ref).abs()
+    mx, mean = err.max().item() / scale, err.mean().item() / scale
+    assert mx <= tol and mean <= mean_tol, f"{what}: max rel err {mx:.3e} (tol {tol}), mean rel err {mean:.3e} (tol {mean_tol})"
+    return mx
+
+
+def rnd(*shape, dev, scale=1.0, dtype=BF):
+    return (torch.randn(*shape, device=dev, dtype=torch.float32) * scale).to(dtype)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def test_hardware_layout_assumptions(ops, dev):
+    o = ops.selftest_layouts(dev).cpu()
+    lane = torch.arange(64)
+    # section 0: mfma 16x16x32: D[r][c] = 16 r + c at col = lane & 15, row = 4 (lane >> 4) + reg
+    for reg in range(4):
+        exp = 16 * (4 * (lane >> 4) + reg) + (lane & 15)
+        assert torch.equal(o[0, :, reg], exp.float()), f"mfma16 C/D layout reg {reg}"
+    # section 1: tr16_b64: lane i of group g gets tile[4g + r][i], r = reg
+    for reg in range(4):
+        exp = 16 * (4 * (lane >> 4) + reg) + (lane & 15)
+        assert torch.equal(o[1, :, reg], exp.float()), f"ds_read_tr16_b64 layout reg {reg}"
+    # section 2: mfma 32x32x16: D[r][c] = B[k = r & 15][c] = 8 (r & 15) + (c & 7), col = lane & 31,
+    #            row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    for reg in range(16):
+        row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        exp = 8 * (row & 15) + ((lane & 31) & 7)
+        assert torch.equal(o[2, :, reg], exp.float()), f"mfma32 C/D layout reg {reg}"
+    # section 3: LDS-DMA writes lane-linearly: lds[lane*8 + j] = src[lane*8 + j]
+    src = torch.arange(512, dtype=torch.float32).to(BF).float()  # what the kernel was fed (bf16-rounded integers)
+    for j in range(8):
+        assert torch.equal(o[3, :, j], src[lane * 8 + j]), "global_load_lds placement"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(128, 128, 64), (200, 136, 72), (1000, 512, 1024), (64, 256, 2048), (37, 8, 8), (300, 384, 40), (515, 1152, 1152)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_gemm_plain(ops, dev, M, N, K, tile):
+    torch.manual_seed(M * 7 + N * 3 + K + tile)
+    a, b = rnd(M, K, dev=dev), rnd(N, K, dev=dev)
+    out = ops.gemm(a, b, tile=tile)
+    ref = (a.float() @ b.float().T).to(BF)
+    close(out, ref, what=f"gemm {M}x{N}x{K} tile {tile}")
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
+def test_gemm_epilogue(ops, dev, act):
+    torch.manual_seed(act)
+    M, N, K = 333, 264, 520
+    a, b = rnd(M, K, dev=dev, scale=0.5), rnd(N, K, dev=dev, scale=0.1)
+    bias, cs, res = rnd(N, dev=dev), rnd(N, dev=dev), rnd(M, N, dev=dev)
+    pre = torch.empty((M, N), dtype=BF, device=dev)
+    out = ops.gemm(a, b, bias=bias, act=act, colscale=cs, residual=res, c_pre=pre)
+    z = (a.float() @ b.float().T + bias.float()).to(BF)
+    close(pre, z, what="c_pre")
+    zf = z.float()
+    h = [zf, torch.nn.functional.gelu(zf), torch.relu(zf), torch.nn.functional.silu(zf), torch.nn.functional.gelu(zf, approximate="tanh")][act]
+    ref = ((h.to(BF).float() * cs.float()).to(BF).float() + res.float()).to(BF)
+    close(out, ref, what=f"epilogue act {act}")
+
+
+def test_gemm_film_epilogue(ops, dev):
+    torch.manual_seed(5)
+    Bn, rows, N, K = 3, 50, 128, 64
+    a, b = rnd(Bn * rows, K, dev=dev), rnd(N, K, dev=dev, scale=0.2)
+    res, gamma, beta = rnd(Bn * rows, N, dev=dev), rnd(Bn, N, dev=dev, scale=0.3), rnd(Bn, N, dev=dev)
+    out = ops.gemm(a, b, residual=res, film=(gamma, beta, rows))
+    x = ((a.float() @ b.float().T).to(BF).float() + res.float()).to(BF).float().view(Bn, rows, N)
+    ref = ((x * (1 + gamma.float()).to(BF).float()[:, None]).to(BF).float() + beta.float()[:, None]).to(BF).view(Bn * rows, N)
+    close(out, ref, what="film epilogue")
+
+
+@pytest.mark.parametrize("groups,K2", [(1, 32), (3, 32), (2, 64), (1, 16)])
+def test_gemm_lora_extension(ops, dev, groups, K2):
+    torch.manual_seed(groups * 10 + K2)
+    M, Ng, K = 300, 256, 192
+    N = Ng * groups
+    a, b = rnd(M, K, dev=dev), rnd(N, K, dev=dev, scale=0.1)
+    t, lb = rnd(M, groups * K2, dev=dev), rnd(N, K2, dev=dev, scale=0.2)
+    out = ops.gemm(a, b, a2=t, b2=lb, k2_group_n=Ng if groups > 1 else 0)
+    ref = a.float() @ b.float().T
+    for g in range(groups):
+        ref[:, g * Ng:(g + 1) * Ng] += t[:, g * K2:(g + 1) * K2].float() @ lb[g * Ng:(g + 1) * Ng].float().T
+    close(out, ref.to(BF), what=f"lora k-extension groups={groups} K2={K2}")
+
+
+@pytest.mark.parametrize("split_k", [2, 8])
+def test_gemm_split_k(ops, dev, split_k):
+    torch.manual_seed(split_k)
+    M, N, K = 64, 384, 4096
+    a, b, bias = rnd(M, K, dev=dev, scale=0.3), rnd(N, K, dev=dev, scale=0.1), rnd(N, dev=dev)
+    out = ops.gemm(a, b, bias=bias, act=2, split_k=split_k)
+    ref = torch.relu((a.float() @ b.float().T + bias.float()).to(BF).float()).to(BF)
+    close(out, ref, what=f"split_k {split_k}")
+
+
+def test_gemm_strided_views(ops, dev):
+    torch.manual_seed(11)
+    big = rnd(100, 512, dev=dev)
+    a = big[:, 128:320]  # lda 512, K = 192
+    b = rnd(64, 192, dev=dev)
+    outbuf = torch.zeros((100, 256), dtype=BF, device=dev)
+    ops.gemm(a, b, out=outbuf[:, 64:128])
+    close(outbuf[:, 64:128], (a.float() @ b.float().T).to(BF), what="strided gemm")
+    assert outbuf[:, :64].abs().max() == 0 and outbuf[:, 128:].abs().max() == 0, "wrote outside the output view"
+
+
+def test_gemm_rejects_bad_arguments(ops, dev):
+    a, b = rnd(16, 12, dev=dev), rnd(16, 12, dev=dev)
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        ops.gemm(a, b)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,P,Q", [(100, 32, 200), (1000, 32, 4096), (777, 264, 32), (64, 136, 264), (4864, 32, 512), (300, 8, 16)])
+def test_gemm_tn(ops, dev, M, P, Q):
+    torch.manual_seed(M + P + Q)
+    x, y = rnd(M, P, dev=dev), rnd(M, Q, dev=dev)
+    ref = 0.5 * (x.float().T @ y.float())
+    acc = torch.ones((P, Q), dtype=torch.float32, device=dev)
+    ops.gemm_tn(x, y, out=acc, alpha=0.5, accumulate=True)
+    close(acc - 1.0, ref, tol=2e-3, mean_tol=2e-4, what=f"gemm_tn atomic {M},{P},{Q}")
+    st = ops.gemm_tn(x, y, alpha=0.5, accumulate=False, out_dtype=torch.float32)
+    close(st, ref, tol=2e-3, mean_tol=2e-4, what="gemm_tn store f32")
+    sb = ops.gemm_tn(x, y, alpha=0.5, accumulate=False, out_dtype=BF)
+    close(sb, ref.to(BF), what="gemm_tn store bf16")
+
+
+def test_gemm_tn_strided(ops, dev):
+    torch.manual_seed(3)
+    t = rnd(500, 96, dev=dev)
+    dy = rnd(500, 384, dev=dev)
+    out = ops.gemm_tn(dy[:, 128:256], t[:, 32:64], accumulate=False)
+    close(out, dy[:, 128:256].float().T @ t[:, 32:64].float(), tol=2e-3, mean_tol=2e-4, what="gemm_tn strided")
+
+
+def test_colsum(ops, dev):
+    x = rnd(1000, 264, dev=dev)
+    out = torch.zeros(264, dtype=torch.float32, device=dev)
+    ops.colsum(x, out)
+    close(out, x.float().sum(0), tol=1e-4, mean_tol=1e-5, what="colsum")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def ref_attention(q, k, v, kv_len, causal, scale):
+    """q,k,v fp32 [B,H,S,hd] (requires_grad ok)."""
+    B, H, S, hd = q.shape
+    s = (q @ k.transpose(-1, -2)) * scale
+    mask = torch.zeros((B, 1, S, S), dtype=torch.bool, device=q.device)
+    if kv_len is not None:
+        mask |= (torch.arange(S, device=q.device)[None, None, None, :] >= kv_len[:, None, None, None])
+    if causal:
+        mask |= torch.triu(torch.ones(S, S, dtype=torch.bool, device=q.device), 1)[None, None]
+    s = s.masked_fill(mask, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return p @ v, torch.logsumexp(s, dim=-1)
+
+
+ATTN_CASES = [
+    # B, H, S, hd, kv_len, causal
+    (2, 2, 64, 128, None, False),
+    (2, 3, 261, 64, None, False),
+    (1, 4, 256, 72, None, False),
+    (3, 2, 300, 128, [300, 250, 17], False),
+    (2, 2, 200, 128, None, True),
+    (2, 2, 333, 128, [333, 100], True),
+    (1, 2, 50, 72, None, False),
+]
+
+
+@pytest.mark.parametrize("B,H,S,hd,kvl,causal", ATTN_CASES)
+def test_attention_fwd_bwd(ops, dev, B, H, S, hd, kvl, causal):
+    torch.manual_seed(B * 100 + S + hd)
+    # fused qkv layout [B*S, 3*H*hd], exactly what the QKV GEMM produces
+    qkv = rnd(B * S, 3 * H * hd, dev=dev)
+    q, k, v = qkv[:, : H * hd], qkv[:, H * hd: 2 * H * hd], qkv[:, 2 * H * hd:]
+    kv_len = None if kvl is None else torch.tensor(kvl, dtype=torch.int32, device=dev)
+    scale = hd ** -0.5
+    out, lse = ops.attn_fwd(q, k, v, B, S, H, hd, kv_len=kv_len, causal=causal)
+
+    def heads(t):
+        return t.float().reshape(B, S, H, hd).permute(0, 2, 1, 3).contiguous().requires_grad_(True)
+
+    qf, kf, vf = heads(q), heads(k), heads(v)
+    ro, rl = ref_attention(qf, kf, vf, None if kv_len is None else kv_len.long(), causal, scale)
+    ref = ro.permute(0, 2, 1, 3).reshape(B * S, H * hd)
+    close(out, ref, tol=2e-2, mean_tol=3e-3, what="attn fwd")
+    close(lse, rl, tol=1e-2, mean_tol=2e-3, what="attn lse")
+
+    do = rnd(B * S, H * hd, dev=dev)
+    dq, dk, dv = ops.attn_bwd(q, k, v, out, do, lse, B, S, H, hd, kv_len=kv_len, causal=causal)
+    ro.backward(do.float().reshape(B, S, H, hd).permute(0, 2, 1, 3))
+
+    def unheads(t):
+        return t.permute(0, 2, 1, 3).reshape(B * S, H * hd)
+
+    close(dv, unheads(vf.grad), tol=3e-2, mean_tol=4e-3, what="attn dV")
+    close(dk, unheads(kf.grad), tol=3e-2, mean_tol=4e-3, what="attn dK")
+    close(dq, unheads(qf.grad), tol=3e-2, mean_tol=4e-3, what="attn dQ")
+
+
+def test_attention_spiked_scores(ops, dev):
+    """Forces large running-max jumps between KV tiles (online-softmax rescale path)."""
+    torch.manual_seed(0)
+    B, H, S, hd = 1, 1, 256, 128
+    q, k, v = rnd(S, hd, dev=dev), rnd(S, hd, dev=dev), rnd(S, hd, dev=dev)
+    k[200] = q[5] * 4.0  # one key in the 4th tile dominates query 5
+    k[70] = q[9] * 3.0
+    out, lse = ops.attn_fwd(q, k, v, B, S, H, hd)
+    ro, rl = ref_attention(q.float()[None, None], k.float()[None, None], v.float()[None, None], None, False, hd ** -0.5)
+    close(out, ro[0, 0], tol=2e-2, mean_tol=3e-3, what="spiked attn")
+    close(lse, rl, tol=1e-2, what="spiked lse")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,dim", [(37, 4096), (64, 28672), (261, 1024), (100, 1152), (5, 64)])
+@pytest.mark.parametrize("rms", [True, False])
+def test_norm_fwd_bwd(ops, dev, rows, dim, rms):
+    torch.manual_seed(rows + dim)
+    x = rnd(rows, dim, dev=dev, scale=2.0) + 0.5
+    w, b = rnd(dim, dev=dev) * 0.1 + 1.0, rnd(dim, dev=dev, scale=0.1)
+    w, b = w.to(BF), b.to(BF)
+    eps = 1e-5 if rms else 1e-6
+    y, mean, rstd = ops.norm_fwd(x, w, None if rms else b, eps=eps, rms=rms)
+    xf = x.float().requires_grad_(True)
+    wf, bf_ = w.float().requires_grad_(True), b.float().requires_grad_(True)
+    if rms:
+        ref = wf * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps))
+    else:
+        ref = torch.nn.functional.layer_norm(xf, (dim,), wf, bf_, eps)
+    close(y, ref, what="norm fwd")
+    dy = rnd(rows, dim, dev=dev)
+    dw = torch.zeros(dim, dtype=torch.float32, device=dev)
+    db = torch.zeros(dim, dtype=torch.float32, device=dev)
+    dx = ops.norm_bwd(x, dy, w, mean, rstd, rms=rms, dweight=dw, dbias=None if rms else db)
+    ref.backward(dy.float())
+    close(dx, xf.grad, what="norm dx")
+    close(dw, wf.grad, tol=2e-3, mean_tol=3e-4, what="norm dw")
+    if not rms:
+        close(db, bf_.grad, tol=2e-3, mean_tol=3e-4, what="norm db")
+    base = rnd(rows, dim, dev=dev)
+    acc = base.clone()
+    ops.norm_bwd(x, dy, w, mean, rstd, rms=rms, dx=acc, dx_accum=True)
+    close(acc, base.float() + xf.grad, what="norm dx accumulate")
+
+
+def test_rope_matches_hf_formula(ops, dev):
+    torch.manual_seed(1)
+    B, S, H, hd = 2, 77, 3, 128
+    qkv = rnd(B * S, 3 * H * hd, dev=dev)
+    orig = qkv.clone()
+    cos, sin = ops.rope_table(S, hd, 10000.0, dev)
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, device=dev, dtype=torch.float32) / hd))
+    ang = torch.arange(S, device=dev, dtype=torch.float32)[:, None] * inv_freq[None]
+    close(cos, ang.cos(), tol=8e-3, what="cos table")
+    close(sin, ang.sin(), tol=8e-3, what="sin table")
+    ops.rope_(qkv, S, 2 * H, hd, cos, sin)
+    c = torch.cat([ang.cos(), ang.cos()], -1).to(BF).float().repeat(B, 1)[:, None, :]  # [B*S, 1, hd]
+    s = torch.cat([ang.sin(), ang.sin()], -1).to(BF).float().repeat(B, 1)[:, None, :]
+    x = orig[:, : 2 * H * hd].float().view(B * S, 2 * H, hd)
+    rot = torch.cat([-x[..., hd // 2:], x[..., : hd // 2]], -1)
+    ref = ((x * c).to(BF).float() + (rot * s).to(BF).float()).to(BF).view(B * S, 2 * H * hd)
+    close(qkv[:, : 2 * H * hd], ref, what="rope")
+    assert torch.equal(qkv[:, 2 * H * hd:], orig[:, 2 * H * hd:]), "rope touched V"
+    ops.rope_(qkv, S, 2 * H, hd, cos, sin, inverse=True)
+    close(qkv[:, : 2 * H * hd], orig[:, : 2 * H * hd], tol=3e-2, mean_tol=5e-3, what="rope inverse")
+
+
+def test_swiglu_and_act_bwd(ops, dev):
+    torch.manual_seed(2)
+    rows, F = 123, 264
+    gu = rnd(rows, 2 * F, dev=dev, scale=1.5)
+    h = ops.swiglu_fwd(gu)
+    gf = gu.float().requires_grad_(True)
+    ref = torch.nn.functional.silu(gf[:, :F]) * gf[:, F:]
+    close(h, ref, what="swiglu fwd")
+    dh = rnd(rows, F, dev=dev)
+    dgu = ops.swiglu_bwd(gu, dh)
+    ref.backward(dh.float())
+    close(dgu, gf.grad, what="swiglu bwd")
+    for act, fn in [(1, torch.nn.functional.gelu), (2, torch.relu), (3, torch.nn.functional.silu),
+                    (4, lambda t: torch.nn.functional.gelu(t, approximate="tanh"))]:
+        z = rnd(rows, F, dev=dev, scale=1.5)
+        zf = z.float().requires_grad_(True)
+        fn(zf).backward(dh.float())
+        close(ops.act_bwd(z, dh, act), zf.grad, what=f"act_bwd {act}")
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def test_vision_front_end_glue(ops, dev):
+    torch.manual_seed(4)
+    B, H, W, patch = 2, 56, 56, 14
+    px = rnd(B, 12, H, W, dev=dev)
+    kp = 592
+    cols = ops.im2col(px, 3, patch, kp)
+    ref = torch.nn.functional.unfold(px[:, 3:6].float(), kernel_size=patch, stride=patch).transpose(1, 2).reshape(B * 16, 588)
+    assert torch.equal(cols[:, :588].float(), ref) and cols[:, 588:].abs().max() == 0, "im2col"
+    dim, npatch, npre = 64, 16, 5
+    patches, pos, prefix = rnd(B * npatch, dim, dev=dev), rnd(npatch, dim, dev=dev), rnd(npre, dim, dev=dev)
+    tok = ops.vit_embed(patches, pos, prefix, B, npatch, dim).view(B, npatch + npre, dim)
+    assert torch.equal(tok[:, :npre], prefix[None].expand(B, -1, -1))
+    close(tok[:, npre:], (patches.view(B, npatch, dim).float() + pos.float()[None]).to(BF), what="vit_embed")
+    tok2 = ops.vit_embed(patches, pos, None, B, npatch, dim).view(B, npatch, dim)
+    close(tok2, (patches.view(B, npatch, dim).float() + pos.float()[None]).to(BF), what="vit_embed no prefix")
+    feat = torch.zeros((B, 2 * npatch, 96), dtype=BF, device=dev)
+    ops.copy_rows(tok, feat, B, npatch, dim, src_batch_stride=(npatch + npre) * dim, src_row0=npre, src_ld=dim,
+                  dst_batch_stride=2 * npatch * 96, dst_row0=npatch, dst_ld=96, dst_col0=32)
+    assert torch.equal(feat[:, npatch:, 32:96], tok[:, npre:]) and feat[:, :npatch].abs().max() == 0 and feat[:, :, :32].abs().max() == 0
+    ops.copy_rows(tok, feat, B, npatch, dim, src_batch_stride=(npatch + npre) * dim, src_row0=npre, src_ld=dim,
+                  dst_batch_stride=2 * npatch * 96, dst_row0=npatch, dst_ld=96, dst_col0=32, accumulate=True)
+    close(feat[:, npatch:, 32:96], 2 * tok[:, npre:].float(), what="copy_rows accumulate")
+    L = 9
+    x = rnd(B, L, dim, dev=dev)
+    mask = torch.tensor([[1, 1, 0, 1, 1, 0, 0, 1, 1], [1, 0, 0, 0, 0, 0, 0, 0, 1]], dtype=torch.uint8, device=dev)
+    mm = ops.masked_mean(x, mask, B, L, dim)
+    ref = torch.stack([x[i][mask[i].bool()].float().mean(0) for i in range(B)])
+    close(mm, ref, what="masked_mean")
+
+
+def test_assemble_and_gather(ops, dev):
+    torch.manual_seed(6)
+    B, Tp, A, D, P, V = 3, 6, 14, 64, 10, 32064
+    L = Tp + A + 1 + 2  # two pad columns
+    ids = torch.randint(3, 31000, (B, L), device=dev)
+    labels = torch.full((B, L), -100, dtype=torch.long, device=dev)
+    for b_, tp in enumerate([Tp, Tp + 2, Tp - 1]):  # ragged prompts, right padded
+        ids[b_, tp: tp + A] = torch.randint(31744, 32000, (A,), device=dev)
+        ids[b_, tp + A] = 2
+        ids[b_, tp + A + 1:] = 32000
+        labels[b_, tp: tp + A + 1] = ids[b_, tp: tp + A + 1]
+    table, patches, noisy = rnd(V, D, dev=dev), rnd(B, P, D, dev=dev), rnd(B, A, D, dev=dev)
+    # reference restatement of modeling_prismatic.py:571-629
+    cum = (labels != -100).cumsum(1)
+    amask = (cum >= 1) & (labels > 31743)
+    emb = table[ids]
+    for use_noisy in (False, True):
+        e = emb.clone()
+        if use_noisy:
+            for b_ in range(B):
+                e[b_, amask[b_]] = noisy[b_]
+        else:
+            e = e * (~amask)[..., None]
+        ref = torch.cat([e[:, :1], patches, e[:, 1:]], 1)
+        out, apos = ops.assemble_multimodal(ids, labels, table, patches, A=A, noisy=noisy if use_noisy else None)
+        assert torch.equal(out, ref), f"assemble (noisy={use_noisy})"
+        for b_ in range(B):
+            assert torch.equal(apos[b_].long(), torch.where(amask[b_])[0]), "action positions"
+    src = rnd(50, D, dev=dev)
+    idx = torch.tensor([3, 49, 0, 7], dtype=torch.int32, device=dev)
+    g = ops.gather_rows(src, idx, D)
+    assert torch.equal(g, src[idx.long()])
+    dst = torch.zeros((50, D), dtype=BF, device=dev)
+    ops.gather_rows(g, idx, D, dst=dst, scatter_add=True)
+    assert torch.equal(dst[idx.long()], g) and dst.abs().sum() == g.abs().sum()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("adim,mse", [(7, False), (14, False), (7, True)])
+def test_head_tail(ops, dev, adim, mse):
+    torch.manual_seed(adim)
+    rows, dim = 64, 4096
+    x, W, b = rnd(rows, dim, dev=dev), rnd(adim, dim, dev=dev, scale=0.02), rnd(adim, dev=dev, scale=0.1)
+    tgt = (torch.rand(rows, adim, device=dev) * 2 - 1).to(BF)
+    loss_sum = torch.zeros(1, dtype=torch.float32, device=dev)
+    pred = ops.head_out_fwd(x, W, b, tgt, loss_sum, mse=mse)
+    xf, Wf, bf_ = x.float().requires_grad_(True), W.float().requires_grad_(True), b.float().requires_grad_(True)
+    rp = xf @ Wf.T + bf_
+    close(pred, rp, what="head pred")
+    rloss = torch.nn.functional.mse_loss(rp, tgt.float()) if mse else torch.nn.functional.l1_loss(rp, tgt.float())
+    close(loss_sum / (rows * adim), rloss.detach().reshape(1), tol=1e-2, mean_tol=1e-2, what="head loss")
+    dW = torch.zeros((adim, dim), dtype=torch.float32, device=dev)
+    db = torch.zeros(adim, dtype=torch.float32, device=dev)
+    dx = ops.head_out_bwd(x, W, pred, tgt, 1.0 / (rows * adim), dW, db, mse=mse)
+    # reference gradient evaluated at the bf16 prediction the kernel used
+    d = (pred.float() - tgt.float()).to(BF).float()
+    gp = (2 * d if mse else torch.sign(d)) / (rows * adim)
+    gp = gp.to(BF).float()
+    close(dx, gp @ W.float(), what="head dx")
+    close(dW, gp.T @ x.float(), tol=2e-3, mean_tol=3e-4, what="head dW")
+    close(db, gp.sum(0), tol=2e-3, mean_tol=3e-4, what="head db")
+
+
+@pytest.mark.parametrize("dtype", [BF, torch.float32])
+def test_adamw_matches_torch(ops, dev, dtype):
+    """Three steps of the fused AdamW against torch.optim.AdamW on CPU (same dtype semantics as the reference, which
+    keeps LoRA/head parameters AND optimizer state in bf16: vla-scripts/finetune.py:952)."""
+    torch.manual_seed(9)
+    n = 10007
+    p0 = (torch.randn(n) * 0.05).to(dtype)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref_p], lr=5e-4)
+    p = p0.clone().to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        g32 = torch.randn(n) * (10.0 ** torch.randint(-4, 1, (n,)).float())
+        ref_p.grad = g32.to(dtype)
+        opt.step()
+        ops.adamw(p, m, v, g32.to(dev), step=step, lr=5e-4)
+        if dtype == BF:
+            mism = (p.cpu().view(torch.int16) != ref_p.data.view(torch.int16)).float().mean().item()
+            assert mism <= 2e-3, f"step {step}: {mism:.2%} of bf16 parameters differ from torch"
+            close(p.cpu(), ref_p.data, tol=8e-3, mean_tol=1e-5, what="adamw bf16 param")
+        else:
+            close(p.cpu(), ref_p.data, tol=1e-6, mean_tol=1e-7, what="adamw f32 param")
+    st = opt.state[ref_p]
+    close(m.cpu(), st["exp_avg"], tol=8e-3 if dtype == BF else 1e-6, mean_tol=1e-4, what="exp_avg")
+    close(v.cpu(), st["exp_avg_sq"], tol=8e-3 if dtype == BF else 1e-6, mean_tol=1e-4, what="exp_avg_sq")
+
+
+def test_transpose_and_casts(ops, dev):
+    x = rnd(100, 264, dev=dev)
+    assert torch.equal(ops.transpose(x), x.T.contiguous())
+    f = torch.randn(1000, device=dev)
+    assert torch.equal(ops.cvt_f32_to_bf16(f, scale=0.5), (f * 0.5).to(BF))
+    assert torch.equal(ops.cvt_bf16_to_f32(x, scale=2.0), x.float() * 2.0)
+    a, b = rnd(64, 128, dev=dev), rnd(64, 128, dev=dev)
+    assert torch.equal(ops.add(a, b), (a.float() + b.float()).to(BF))
+    s = rnd(128, dev=dev)
+    assert torch.equal(ops.colscale(a, s), (a.float() * s.float()).to(BF))
