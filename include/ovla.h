@@ -52,7 +52,7 @@ int ovla_check_device(int device);
  * backward data gradient dX = dY . W (A = dY, B = W^T).
  *
  * Epilogue order (each step rounds to bf16 like the reference's separate PyTorch ops do):
- *   v = acc;  v += bias[n];  [C_pre = v];  v = act(v);  v *= colscale[n];  v += residual[m,n];
+ *   v = alpha * acc;  v += bias[n];  [C_pre = v];  v = act(v);  v *= colscale[n];  v += residual[m,n];
  *   v = v * (1 + film_gamma[m / film_rows, n]) + film_beta[...]  ->  C
  * Requirements: K % 8 == 0, K2 % 8 == 0, N % 8 == 0, ld* % 8 == 0, 16-byte aligned base pointers.
  * split_k > 1 needs `workspace` of ovla_gemm_workspace_bytes() bytes.
@@ -77,6 +77,7 @@ typedef struct {
   int32_t act;
   int32_t split_k;               /* <=1: none */
   int32_t tile;                  /* 0: auto; otherwise forces a tile configuration (tests / tuning) */
+  float alpha;                   /* scales the accumulator (LoRA alpha/r); 0 means 1 */
   void* workspace;               /* fp32 [split_k, M, N] when split_k > 1 */
 } ovla_gemm_args;
 
@@ -219,8 +220,9 @@ int ovla_masked_mean(const ovla_masked_mean_args* a, void* stream);
  *   out[b, 1 .. P]       = patches[b, :]            (P = projected patches + proprio (+ timestep) tokens)
  *   out[b, P+1+i]        = action_mask[b,1+i] ? (noisy ? noisy[b, slot] : 0) : embed[ids[b, 1+i]]
  * action_mask is computed on device from labels exactly as train_utils.get_current_action_mask | get_next_actions_mask
- * (cumsum of labels != -100, labels > 31743); `action_index` receives, per batch row, the A sequence positions
- * (in the assembled sequence) of the action slots, used by ovla_gather_rows for the shift-by-one hidden gather.
+ * (cumsum of labels != -100, labels > 31743); `action_pos` receives, per batch row and action slot, the flattened row
+ * b*(P+L) + (P + i) - 1 of the assembled sequence whose final hidden state PREDICTS that slot (i = text index of the
+ * slot; shift-by-one of finetune.py:385-394 / modeling_prismatic.py:915-920), ready for ovla_gather_rows.
  */
 typedef struct {
   const int64_t* ids; const int64_t* labels;   /* [B, L] */
@@ -228,7 +230,7 @@ typedef struct {
   const void* patches;                          /* bf16 [B, P, D] */
   const void* noisy;                            /* optional bf16 [B, A, D] */
   void* out;                                    /* bf16 [B, P+L, D] */
-  int32_t* action_pos;                          /* optional int32 [B, A]: text-relative index of each action slot */
+  int32_t* action_pos;                          /* optional int32 [B, A]: predicting row of each action slot */
   int32_t B, L, P, D, A, vocab;
   int32_t ignore_index, action_token_begin, action_dim;
 } ovla_assemble_args;

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(const int64_t* __restrict
       }
       sh_is_action = is_action;
       sh_slot = slot;
-      if (is_action && action_pos && slot < A) action_pos[(int64_t)b * A + slot] = i;
+      if (is_action && action_pos && slot < A) action_pos[(int64_t)b * A + slot] = b * S + P + i - 1;  // row whose hidden state predicts this slot
     }
     __syncthreads();
     if (sh_is_action) {

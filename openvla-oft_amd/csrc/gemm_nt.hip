@@ -33,6 +33,7 @@ struct GemmParams {
   const bf16_bits *film_gamma, *film_beta;
   int film_rows;
   int M, N, K, K2, k2_group_n, act, split_k;
+  float alpha;
   float* ws;
   int tiles_m, tiles_n, T1, T2;
 };
@@ -64,6 +65,7 @@ OVLA_DEV bf16x8_bits lds_frag(const bf16_bits* tile, int row, int chunk) {
 
 // Epilogue on 4 consecutive columns n..n+3 of row m.  Every step rounds to bf16, as the reference's separate ops do.
 OVLA_DEV void epilogue_store(const GemmParams& p, int m, int n, f32x4 v) {
+  v *= p.alpha;
   if (p.bias) {
     const bf16x4_bits b = *reinterpret_cast<const bf16x4_bits*>(p.bias + n);
 #pragma unroll
@@ -311,6 +313,7 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   p.M = a->M; p.N = a->N; p.K = a->K; p.K2 = a->K2 > 0 ? a->K2 : 0;
   p.k2_group_n = a->k2_group_n; p.act = a->act; p.split_k = a->split_k > 1 ? a->split_k : 1;
   p.ws = (float*)a->workspace;
+  p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
   p.T1 = cdiv(p.K, BK); p.T2 = p.K2 > 0 ? cdiv(p.K2, BK) : 0;
   if (p.split_k > p.T1 + p.T2) p.split_k = p.T1 + p.T2;
 

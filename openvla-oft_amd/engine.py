@@ -1,0 +1,698 @@
+"""Execution engine of the OpenVLA-OFT action-chunk path on MI355X.
+
+Host-side orchestration only: every tensor op below is a hand-written gfx950 kernel reached through the C-ABI
+(`ops.py` -> libovla_hip.so).  PyTorch supplies device memory and the HIP stream.  Forward and backward are written
+out explicitly per block (no autograd tape, no tracing compiler): each `fwd` returns the activations its `bwd` needs.
+
+HBM layout (sized for 288 GB):
+  * frozen base weights are resident twice, as W [out, in] and W^T [in, out], so forward AND data-gradient GEMMs are
+    the same K-contiguous "NT" kernel (no transposed-operand kernel variants, no per-step transposes);
+  * Llama q|k|v and gate|up are fused along N; their LoRA pairs are stacked the same way and ride in the GEMM's
+    K-extension (one launch per fused linear);
+  * all trainable tensors (LoRA A/B, action head, projectors) are views into two flat buffers (bf16 / fp32) with matching
+    flat fp32 gradient buffers: one fused AdamW launch and one RCCL all-reduce per dtype bucket;
+  * activations for the backward stay resident in bf16 (no recompute at 288 GB).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .config import VLAConfig, VitConfig
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+# ======================================================================================================================
+# trainable-parameter store
+# ======================================================================================================================
+class Param:
+    """Handle to one trainable tensor living in a flat buffer (`data`), with its fp32 gradient view (`grad`)."""
+
+    def __init__(self, name, init: torch.Tensor):
+        self.name, self.shape, self.dtype = name, tuple(init.shape), init.dtype
+        self._init = init
+        self.data: Optional[torch.Tensor] = None
+        self.grad: Optional[torch.Tensor] = None
+        self.offset = 0
+
+    @property
+    def numel(self):
+        return math.prod(self.shape)
+
+
+class ParamStore:
+    ALIGN = 64  # elements; keeps every view 128-byte aligned
+
+    def __init__(self, device):
+        self.device = device
+        self.params: List[Param] = []
+        self.flat: Dict[torch.dtype, torch.Tensor] = {}
+        self.flat_grad: Dict[torch.dtype, torch.Tensor] = {}
+        self.exp_avg: Dict[torch.dtype, torch.Tensor] = {}
+        self.exp_avg_sq: Dict[torch.dtype, torch.Tensor] = {}
+        self.step = 0
+        self.finalized = False
+
+    def add(self, name: str, init: torch.Tensor) -> Param:
+        assert not self.finalized and init.dtype in (BF16, F32)
+        p = Param(name, init.to(self.device))
+        self.params.append(p)
+        return p
+
+    def finalize(self):
+        """Lays the tensors out in REVERSE registration order (= the order the backward produces their gradients), so
+        gradient buckets complete front to back."""
+        for dtype in (BF16, F32):
+            group = [p for p in reversed(self.params) if p.dtype == dtype]
+            total = 0
+            for p in group:
+                p.offset = total
+                total += (p.numel + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            if total == 0:
+                continue
+            flat = torch.zeros(total, dtype=dtype, device=self.device)
+            grad = torch.zeros(total, dtype=F32, device=self.device)
+            for p in group:
+                p.data = flat[p.offset: p.offset + p.numel].view(p.shape)
+                p.data.copy_(p._init)
+                p.grad = grad[p.offset: p.offset + p.numel].view(p.shape)
+                p._init = None
+            self.flat[dtype], self.flat_grad[dtype] = flat, grad
+        self.finalized = True
+
+    def init_optimizer(self):
+        for dtype, flat in self.flat.items():
+            self.exp_avg[dtype] = torch.zeros_like(flat)
+            self.exp_avg_sq[dtype] = torch.zeros_like(flat)
+        self.step = 0
+
+    def zero_grad(self):
+        for g in self.flat_grad.values():
+            g.zero_()
+
+    def adamw_step(self, lr: float, *, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0):
+        """torch.optim.AdamW(trainable_params, lr) of vla-scripts/finetune.py:952 as one fused launch per dtype."""
+        if not self.exp_avg:
+            self.init_optimizer()
+        self.step += 1
+        for dtype, flat in self.flat.items():
+            ops.adamw(flat, self.exp_avg[dtype], self.exp_avg_sq[dtype], self.flat_grad[dtype], step=self.step, lr=lr, beta1=beta1,
+                      beta2=beta2, eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
+
+    def num_trainable(self):
+        return sum(p.numel for p in self.params)
+
+    def named(self) -> Dict[str, Param]:
+        return {p.name: p for p in self.params}
+
+
+# ======================================================================================================================
+# linears
+# ======================================================================================================================
+class LoraLinear:
+    """Frozen nn.Linear (+ optional bias) with peft-style LoRA adapters; `groups` fused sub-linears share the input.
+
+    forward:  t_s = s * x A^T ;  y = x W^T (+ bias) + t_s B^T                     (one K-extended GEMM)
+    backward: dt  = s * dy_g B_g   (per group);  dx = dy W + dt A                  (one K-extended GEMM on W^T / A^T)
+              dB_g += dy_g^T t_s,g ;  dA += dt^T x                                 (TN GEMMs, fp32 accumulate)
+    """
+
+    def __init__(self, store: Optional[ParamStore], name: str, W: torch.Tensor, bias: Optional[torch.Tensor], lora_A: Optional[torch.Tensor],
+                 lora_B: Optional[torch.Tensor], groups: int, scale: float, need_dgrad: bool = True, ref_names=None):
+        self.name, self.W, self.bias, self.groups, self.scale = name, W.contiguous(), bias, groups, scale
+        self.ref_names = ref_names or [name]   # the reference's nn.Linear module path of every fused group
+        self.out_f, self.in_f = W.shape
+        self.group_n = self.out_f // groups
+        self.WT = ops.transpose(self.W) if need_dgrad else None
+        self.has_lora = lora_A is not None
+        if self.has_lora:
+            self.r = lora_A.shape[0] // groups
+            assert lora_A.shape == (groups * self.r, self.in_f) and lora_B.shape == (self.out_f, self.r)
+            self.A = store.add(name + ".lora_A", lora_A.to(BF16))
+            self.B = store.add(name + ".lora_B", lora_B.to(BF16))
+            self.AT = None   # [in, G*r]   derived
+            self.BT = None   # list of [r, group_n] derived
+
+    def refresh_derived(self):
+        if not self.has_lora:
+            return
+        self.AT = ops.transpose(self.A.data, self.AT)
+        if self.BT is None:
+            self.BT = [None] * self.groups
+        for g in range(self.groups):
+            self.BT[g] = ops.transpose(self.B.data[g * self.group_n:(g + 1) * self.group_n], self.BT[g])
+
+    def export(self, kind: str = "data") -> Dict[str, torch.Tensor]:
+        """Trainable tensors (kind='data') or their fp32 gradients (kind='grad') under the reference/peft-style names."""
+        out = {}
+        if self.has_lora:
+            A, Bm = getattr(self.A, kind), getattr(self.B, kind)
+            for g, rn in enumerate(self.ref_names):
+                out[rn + ".lora_A.weight"] = A[g * self.r:(g + 1) * self.r]
+                out[rn + ".lora_B.weight"] = Bm[g * self.group_n:(g + 1) * self.group_n]
+        return out
+
+    def fwd(self, x, *, act=0, residual=None, colscale=None, c_pre=None, film=None, out=None):
+        """x [M, in] -> (y [M, out], saved)."""
+        t_s = None
+        if self.has_lora:
+            t_s = ops.gemm(x, self.A.data, alpha=self.scale)
+            y = ops.gemm(x, self.W, out=out, bias=self.bias, act=act, residual=residual, colscale=colscale, c_pre=c_pre, film=film,
+                         a2=t_s, b2=self.B.data, k2_group_n=self.group_n if self.groups > 1 else 0)
+        else:
+            y = ops.gemm(x, self.W, out=out, bias=self.bias, act=act, residual=residual, colscale=colscale, c_pre=c_pre, film=film)
+        return y, (x, t_s)
+
+    def bwd(self, dy, saved, need_dx=True):
+        """dy [M, out] (gradient w.r.t. the pre-activation linear output) -> dx [M, in]; accumulates LoRA grads."""
+        x, t_s = saved
+        dx = None
+        if self.has_lora:
+            M, r, G, gn = dy.shape[0], self.r, self.groups, self.group_n
+            dt = torch.empty((M, G * r), dtype=BF16, device=dy.device)
+            for g in range(G):
+                ops.gemm(dy[:, g * gn:(g + 1) * gn], self.BT[g], out=dt[:, g * r:(g + 1) * r], alpha=self.scale)
+                ops.gemm_tn(dy[:, g * gn:(g + 1) * gn], t_s[:, g * r:(g + 1) * r], out=self.B.grad[g * gn:(g + 1) * gn])
+            ops.gemm_tn(dt, x, out=self.A.grad)
+            if need_dx:
+                dx = ops.gemm(dy, self.WT, a2=dt, b2=self.AT)
+        elif need_dx:
+            dx = ops.gemm(dy, self.WT)
+        return dx
+
+
+class FullLinear:
+    """Fully trainable nn.Linear (action head, proprio / noisy-action projector, FiLM).  `master_fp32`: parameters live
+    in fp32 (the reference never casts these modules, finetune.py:895-901) and a bf16 compute copy is refreshed after
+    each optimizer step -- what autocast does on every call.  The input width is zero-padded to a multiple of 8 (the
+    GEMM's K granularity; proprio_dim 8, noisy-action dim 1): the padded columns see zero inputs, get zero gradients
+    and stay zero, and are sliced off on export."""
+
+    def __init__(self, store: ParamStore, name: str, W: torch.Tensor, bias: Optional[torch.Tensor], master_fp32: bool = False):
+        dt = F32 if master_fp32 else BF16
+        self.name, self.master_fp32 = name, master_fp32
+        self.out_f, self.in_f = W.shape
+        self.in_pad = (self.in_f + 7) // 8 * 8
+        Wp = torch.zeros((self.out_f, self.in_pad), dtype=dt, device=W.device)
+        Wp[:, : self.in_f] = W.to(dt)
+        self.W = store.add(name + ".weight", Wp)
+        self.b = store.add(name + ".bias", bias.to(dt)) if bias is not None else None
+        self.Wc = self.bc = None
+
+    def refresh_derived(self):
+        if self.master_fp32:
+            self.Wc = ops.cvt_f32_to_bf16(self.W.data, self.Wc)
+            if self.b is not None:
+                self.bc = ops.cvt_f32_to_bf16(self.b.data, self.bc)
+        else:
+            self.Wc, self.bc = self.W.data, (None if self.b is None else self.b.data)
+
+    def export(self, kind: str = "data") -> Dict[str, torch.Tensor]:
+        out = {self.name + ".weight": getattr(self.W, kind)[:, : self.in_f]}
+        if self.b is not None:
+            out[self.name + ".bias"] = getattr(self.b, kind)
+        return out
+
+    def fwd(self, x, *, act=0, residual=None, c_pre=None, split_k=1):
+        y = ops.gemm(x, self.Wc, bias=self.bc, act=act, residual=residual, c_pre=c_pre, split_k=split_k)
+        return y, (x,)
+
+    def bwd(self, dy, saved, need_dx=True):
+        (x,) = saved
+        M = dy.shape[0]
+        ops.gemm_tn(dy, x, out=self.W.grad)
+        if self.b is not None:
+            ops.colsum(dy, self.b.grad)
+        if not need_dx:
+            return None
+        if M % 8 != 0:
+            raise RuntimeError(f"{self.name}: row count {M} must be a multiple of 8 for the data gradient")
+        dyT = ops.transpose(dy)                                               # [out, M]
+        return ops.gemm_tn(dyT, self.Wc, accumulate=False, out_dtype=BF16)   # [M, in] = dy . W  (contract over `out`)
+
+
+# ======================================================================================================================
+# ViT (timm VisionTransformer blocks; reference call site modeling_prismatic.py:127-139,186-227)
+# ======================================================================================================================
+ACT_ID = {"gelu": ops.ACT_GELU, "gelu_tanh": ops.ACT_GELU_TANH}
+
+
+class VitTower:
+    def __init__(self, store, prefix: str, vc: VitConfig, get, cfg: VLAConfig, lora: bool, film: bool = False):
+        self.vc, self.prefix = vc, prefix
+        w = get(prefix + "patch_embed.proj.weight").reshape(vc.dim, -1)                 # [dim, 3*p*p]
+        self.patch_w = torch.zeros((vc.dim, vc.patch_k), dtype=BF16, device=w.device)
+        self.patch_w[:, : w.shape[1]] = w
+        self.patch_b = get(prefix + "patch_embed.proj.bias")
+        self.pos = get(prefix + "pos_embed").reshape(vc.n_patches, vc.dim).contiguous()
+        pre = []
+        if vc.n_prefix > 0:
+            pre.append(get(prefix + "cls_token").reshape(1, vc.dim))
+            if vc.n_prefix > 1:
+                pre.append(get(prefix + "reg_token").reshape(vc.n_prefix - 1, vc.dim))
+        self.prefix_tokens = torch.cat(pre, 0).contiguous() if pre else None
+        self.act = ACT_ID[vc.act]
+        self.blocks = []
+        s = cfg.lora_scale
+
+        def L(name, groups=1):
+            A = get(name + ".lora_A.weight") if lora else None
+            Bm = get(name + ".lora_B.weight") if lora else None
+            return LoraLinear(store, name, get(name + ".weight"), get(name + ".bias"), A, Bm, groups, s)
+
+        # only blocks 0 .. depth-2 are ever used: the forward returns the output of block depth-2
+        # (get_intermediate_layers(n={depth-2})); the last block's output is discarded (film_vit_wrapper.py:124-137)
+        for i in range(vc.depth - 1):
+            p = f"{prefix}blocks.{i}."
+            blk = dict(ln1_w=get(p + "norm1.weight"), ln1_b=get(p + "norm1.bias"), ln2_w=get(p + "norm2.weight"), ln2_b=get(p + "norm2.bias"),
+                       qkv=L(p + "attn.qkv"), proj=L(p + "attn.proj"), fc1=L(p + "mlp.fc1"), fc2=L(p + "mlp.fc2"),
+                       ls1=get(p + "ls1.scale_factor") if vc.layerscale else None, ls2=get(p + "ls2.scale_factor") if vc.layerscale else None)
+            self.blocks.append(blk)
+
+    def linears(self):
+        for b in self.blocks:
+            yield from (b["qkv"], b["proj"], b["fc1"], b["fc2"])
+
+    def fwd(self, pixels, c0: int, train: bool):
+        """pixels bf16 [B, C, H, W]; channels [c0, c0+3).  Returns (tokens [B*T, dim] after block depth-2, saved)."""
+        vc = self.vc
+        B = pixels.shape[0]
+        cols = ops.im2col(pixels, c0, vc.patch, vc.patch_k)
+        patches = ops.gemm(cols, self.patch_w, bias=self.patch_b)
+        x = ops.vit_embed(patches, self.pos, self.prefix_tokens, B, vc.n_patches, vc.dim)
+        T = vc.n_patches + vc.n_prefix
+        H, hd = vc.heads, vc.head_dim
+        saved = []
+        for blk in self.blocks:
+            h1, mean1, rstd1 = ops.norm_fwd(x, blk["ln1_w"], blk["ln1_b"], eps=vc.eps, rms=False, save_stats=train)
+            qkv, s_qkv = blk["qkv"].fwd(h1)
+            o, lse = ops.attn_fwd(qkv[:, : vc.dim], qkv[:, vc.dim: 2 * vc.dim], qkv[:, 2 * vc.dim:], B, T, H, hd)
+            x2, s_proj = blk["proj"].fwd(o, residual=x, colscale=blk["ls1"])
+            h2, mean2, rstd2 = ops.norm_fwd(x2, blk["ln2_w"], blk["ln2_b"], eps=vc.eps, rms=False, save_stats=train)
+            z = torch.empty((h2.shape[0], vc.mlp_hidden), dtype=BF16, device=h2.device) if train else None
+            hmid, s_fc1 = blk["fc1"].fwd(h2, act=self.act, c_pre=z)
+            x3, s_fc2 = blk["fc2"].fwd(hmid, residual=x2, colscale=blk["ls2"])
+            if train:
+                saved.append((x, mean1, rstd1, s_qkv, qkv, o, lse, s_proj, x2, mean2, rstd2, s_fc1, z, s_fc2))
+            x = x3
+        return x, (saved, B)
+
+    def bwd(self, dx, saved_all):
+        """dx [B*T, dim]: gradient w.r.t. the tower output (prefix rows already zero).  Pixels need no gradient."""
+        vc = self.vc
+        saved, B = saved_all
+        T = vc.n_patches + vc.n_prefix
+        H, hd = vc.heads, vc.head_dim
+        for blk, sv in zip(reversed(self.blocks), reversed(saved)):
+            x, mean1, rstd1, s_qkv, qkv, o, lse, s_proj, x2, mean2, rstd2, s_fc1, z, s_fc2 = sv
+            # x3 = x2 + ls2 * fc2(act(fc1(ln2(x2))))
+            d = ops.colscale(dx, blk["ls2"]) if blk["ls2"] is not None else dx
+            dh = blk["fc2"].bwd(d, s_fc2)
+            dz = ops.act_bwd(z, dh, self.act)
+            dh2 = blk["fc1"].bwd(dz, s_fc1)
+            ops.norm_bwd(x2, dh2, blk["ln2_w"], mean2, rstd2, rms=False, dx=dx, dx_accum=True)       # dx now = d x2
+            # x2 = x + ls1 * proj(attn(qkv(ln1(x))))
+            d = ops.colscale(dx, blk["ls1"]) if blk["ls1"] is not None else dx
+            do = blk["proj"].bwd(d, s_proj)
+            dqkv = torch.empty_like(qkv)
+            D = vc.dim
+            ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, do, lse, B, T, H, hd, dq=dqkv[:, :D], dk=dqkv[:, D:2 * D],
+                         dv=dqkv[:, 2 * D:])
+            dh1 = blk["qkv"].bwd(dqkv, s_qkv)
+            ops.norm_bwd(x, dh1, blk["ln1_w"], mean1, rstd1, rms=False, dx=dx, dx_accum=True)        # dx now = d x
+        return None  # patch embedding / position embedding are frozen and the pixels need no gradient
+
+
+# ======================================================================================================================
+# Llama decoder stack (transformers LlamaModel; reference call site modeling_prismatic.py:632-643)
+# ======================================================================================================================
+class LlamaStack:
+    def __init__(self, store, cfg: VLAConfig, get, lora: bool):
+        self.cfg = cfg
+        D, F, s = cfg.llm_dim, cfg.llm_ff, cfg.lora_scale
+        self.layers = []
+        for i in range(cfg.llm_layers):
+            p = f"language_model.model.layers.{i}."
+
+            def fused(names, sub):
+                W = torch.cat([get(p + sub + n + ".weight") for n in names], 0)
+                A = torch.cat([get(p + sub + n + ".lora_A.weight") for n in names], 0) if lora else None
+                Bm = torch.cat([get(p + sub + n + ".lora_B.weight") for n in names], 0) if lora else None
+                return LoraLinear(store, p + sub + "+".join(names), W, None, A, Bm, len(names), s, ref_names=[p + sub + n for n in names])
+
+            self.layers.append(dict(
+                qkv=fused(["q_proj", "k_proj", "v_proj"], "self_attn."), o=fused(["o_proj"], "self_attn."),
+                gu=fused(["gate_proj", "up_proj"], "mlp."), down=fused(["down_proj"], "mlp."),
+                n1=get(p + "input_layernorm.weight"), n2=get(p + "post_attention_layernorm.weight")))
+        self.norm_w = get("language_model.model.norm.weight")
+        self.hd = D // cfg.llm_heads
+        self.cos = self.sin = None
+
+    def linears(self):
+        for l in self.layers:
+            yield from (l["qkv"], l["o"], l["gu"], l["down"])
+
+    def _tables(self, S, device):
+        if self.cos is None or self.cos.shape[0] < S:
+            n = max(S, self.cfg.max_positions)
+            self.cos, self.sin = ops.rope_table(n, self.hd, self.cfg.rope_theta, device)
+        return self.cos, self.sin
+
+    def fwd(self, x, B: int, S: int, kv_len, train: bool):
+        """x bf16 [B*S, D] (inputs_embeds) -> (hidden_states[-1] [B*S, D] (post final norm), saved)."""
+        cfg = self.cfg
+        D, H, hd, F = cfg.llm_dim, cfg.llm_heads, self.hd, cfg.llm_ff
+        cos, sin = self._tables(S, x.device)
+        causal = cfg.mask_mode == "causal"
+        saved = []
+        for l in self.layers:
+            h1, _, r1 = ops.norm_fwd(x, l["n1"], eps=cfg.rms_eps, rms=True, save_stats=train)
+            qkv, s_qkv = l["qkv"].fwd(h1)
+            ops.rope_(qkv, S, 2 * H, hd, cos, sin)
+            o, lse = ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, S, H, hd, kv_len=kv_len, causal=causal)
+            x2, s_o = l["o"].fwd(o, residual=x)
+            h2, _, r2 = ops.norm_fwd(x2, l["n2"], eps=cfg.rms_eps, rms=True, save_stats=train)
+            gu, s_gu = l["gu"].fwd(h2)
+            hm = ops.swiglu_fwd(gu)
+            x3, s_d = l["down"].fwd(hm, residual=x2)
+            if train:
+                saved.append((x, r1, s_qkv, qkv, o, lse, s_o, x2, r2, s_gu, gu, s_d))
+            x = x3
+        out, _, rf = ops.norm_fwd(x, self.norm_w, eps=cfg.rms_eps, rms=True, save_stats=train)
+        return out, (saved, x, rf, B, S, kv_len)
+
+    def bwd(self, dout, saved_all):
+        """dout [B*S, D] gradient of hidden_states[-1] -> gradient of inputs_embeds (in a fresh buffer)."""
+        cfg = self.cfg
+        saved, x_last, rf, B, S, kv_len = saved_all
+        D, H, hd, F = cfg.llm_dim, cfg.llm_heads, self.hd, cfg.llm_ff
+        causal = cfg.mask_mode == "causal"
+        dx = ops.norm_bwd(x_last, dout, self.norm_w, None, rf, rms=True)
+        for l, sv in zip(reversed(self.layers), reversed(saved)):
+            x, r1, s_qkv, qkv, o, lse, s_o, x2, r2, s_gu, gu, s_d = sv
+            dh = l["down"].bwd(dx, s_d)
+            dgu = ops.swiglu_bwd(gu, dh)
+            dh2 = l["gu"].bwd(dgu, s_gu)
+            ops.norm_bwd(x2, dh2, l["n2"], None, r2, rms=True, dx=dx, dx_accum=True)                   # dx = d x2
+            do = l["o"].bwd(dx, s_o)
+            dqkv = torch.empty_like(qkv)
+            ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, do, lse, B, S, H, hd, kv_len=kv_len, causal=causal,
+                         dq=dqkv[:, :D], dk=dqkv[:, D:2 * D], dv=dqkv[:, 2 * D:])
+            ops.rope_(dqkv, S, 2 * H, hd, self.cos, self.sin, inverse=True)
+            dh1 = l["qkv"].bwd(dqkv, s_qkv)
+            ops.norm_bwd(x, dh1, l["n1"], None, r1, rms=True, dx=dx, dx_accum=True)                    # dx = d x
+        return dx
+
+
+# ======================================================================================================================
+# MLPResNet action head (prismatic/models/action_heads.py:38-107; L1 loss finetune.py:400, MSE :407)
+# ======================================================================================================================
+class ActionHead:
+    def __init__(self, store, cfg: VLAConfig, get, prefix: str):
+        D, A = cfg.llm_dim, cfg.action_dim
+        self.cfg, self.prefix = cfg, prefix
+        self.ln1_w = store.add(prefix + "layer_norm1.weight", get(prefix + "layer_norm1.weight"))
+        self.ln1_b = store.add(prefix + "layer_norm1.bias", get(prefix + "layer_norm1.bias"))
+        self.fc1 = FullLinear(store, prefix + "fc1", get(prefix + "fc1.weight"), get(prefix + "fc1.bias"))
+        self.blocks = []
+        for b in range(2):
+            q = f"{prefix}mlp_resnet_blocks.{b}.ffn."
+            self.blocks.append(dict(ln_w=store.add(q + "0.weight", get(q + "0.weight")), ln_b=store.add(q + "0.bias", get(q + "0.bias")),
+                                    fc=FullLinear(store, q + "1", get(q + "1.weight"), get(q + "1.bias"))))
+        self.ln2_w = store.add(prefix + "layer_norm2.weight", get(prefix + "layer_norm2.weight"))
+        self.ln2_b = store.add(prefix + "layer_norm2.bias", get(prefix + "layer_norm2.bias"))
+        self.out_w = store.add(prefix + "fc2.weight", get(prefix + "fc2.weight"))
+        self.out_b = store.add(prefix + "fc2.bias", get(prefix + "fc2.bias"))
+
+    def linears(self):
+        yield self.fc1
+        for b in self.blocks:
+            yield b["fc"]
+
+    def plain_params(self):
+        yield from (self.ln1_w, self.ln1_b, self.ln2_w, self.ln2_b, self.out_w, self.out_b)
+        for b in self.blocks:
+            yield from (b["ln_w"], b["ln_b"])
+
+    def fwd(self, actions_hidden, target=None, mse=False, train=False):
+        """actions_hidden bf16 [B*A_tokens, D] (row-major (b, token)) == reshape(B, chunk, action_dim*D).
+        Returns (pred [B*chunk, action_dim], loss_sum fp32[1] or None, saved)."""
+        cfg = self.cfg
+        rows = actions_hidden.shape[0] // cfg.action_dim
+        x0 = actions_hidden.view(rows, cfg.action_dim * cfg.llm_dim)
+        h0, m0, r0 = ops.norm_fwd(x0, self.ln1_w.data, self.ln1_b.data, eps=1e-5, rms=False, save_stats=train)
+        z1 = torch.empty((rows, cfg.llm_dim), dtype=BF16, device=x0.device) if train else None
+        split = 8 if rows <= 256 else 1      # small-M weight stream: split K over the chip
+        x, s1 = self.fc1.fwd(h0, act=ops.ACT_RELU, c_pre=z1, split_k=split)
+        blocks_saved = []
+        for b in self.blocks:
+            hb, mb, rb = ops.norm_fwd(x, b["ln_w"].data, b["ln_b"].data, eps=1e-5, rms=False, save_stats=train)
+            # x_new = relu(fc(ln(x))) + x : epilogue applies the activation before the residual add
+            zb = torch.empty_like(x) if train else None
+            xn, sb = b["fc"].fwd(hb, act=ops.ACT_RELU, residual=x, c_pre=zb, split_k=2 if rows <= 256 else 1)
+            blocks_saved.append((x, mb, rb, zb, sb))
+            x = xn
+        h2, m2, r2 = ops.norm_fwd(x, self.ln2_w.data, self.ln2_b.data, eps=1e-5, rms=False, save_stats=train)
+        loss_sum = torch.zeros(1, dtype=F32, device=x0.device) if target is not None else None
+        pred = ops.head_out_fwd(h2, self.out_w.data, self.out_b.data, target, loss_sum, mse=mse)
+        saved = (x0, m0, r0, z1, s1, blocks_saved, x, m2, r2, h2, pred, target, mse) if train else None
+        return pred, loss_sum, saved
+
+    def bwd(self, saved, dloss: float = 1.0):
+        """Returns d(actions_hidden) [B*A_tokens, D]; accumulates the head's gradients."""
+        cfg = self.cfg
+        x0, m0, r0, z1, s1, blocks_saved, xl, m2, r2, h2, pred, target, mse = saved
+        rows = x0.shape[0]
+        dh2 = ops.head_out_bwd(h2, self.out_w.data, pred, target, dloss / (rows * cfg.action_dim), self.out_w.grad, self.out_b.grad, mse=mse)
+        dx = ops.norm_bwd(xl, dh2, self.ln2_w.data, m2, r2, rms=False, dweight=self.ln2_w.grad, dbias=self.ln2_b.grad)
+        for b, (xin, mb, rb, zb, sb) in zip(reversed(self.blocks), reversed(blocks_saved)):
+            dz = ops.act_bwd(zb, dx, ops.ACT_RELU)
+            dhb = b["fc"].bwd(dz, sb)
+            ops.norm_bwd(xin, dhb, b["ln_w"].data, mb, rb, rms=False, dx=dx, dx_accum=True, dweight=b["ln_w"].grad, dbias=b["ln_b"].grad)
+        dz1 = ops.act_bwd(z1, dx, ops.ACT_RELU)
+        dh0 = self.fc1.bwd(dz1, s1)
+        dx0 = ops.norm_bwd(x0, dh0, self.ln1_w.data, m0, r0, rms=False, dweight=self.ln1_w.grad, dbias=self.ln1_b.grad)
+        return dx0.view(rows * cfg.action_dim, cfg.llm_dim)
+
+
+class MlpProjector:
+    """fc1 -> GELU -> fc2 with fully trainable fp32 parameters (ProprioProjector / NoisyActionProjector,
+    prismatic/models/projectors.py:6-49)."""
+
+    def __init__(self, store, get, prefix: str):
+        self.fc1 = FullLinear(store, prefix + "fc1", get(prefix + "fc1.weight").float(), get(prefix + "fc1.bias").float(), master_fp32=True)
+        self.fc2 = FullLinear(store, prefix + "fc2", get(prefix + "fc2.weight").float(), get(prefix + "fc2.bias").float(), master_fp32=True)
+
+    def linears(self):
+        return (self.fc1, self.fc2)
+
+    def fwd(self, x, train: bool):
+        """x bf16 [rows, in] (rows padded to a multiple of 8 by the caller)."""
+        if x.shape[1] != self.fc1.in_pad:
+            xp = torch.zeros((x.shape[0], self.fc1.in_pad), dtype=BF16, device=x.device)
+            xp[:, : x.shape[1]] = x
+            x = xp
+        z = torch.empty((x.shape[0], self.fc1.out_f), dtype=BF16, device=x.device) if train else None
+        h, s1 = self.fc1.fwd(x, act=ops.ACT_GELU, c_pre=z)
+        y, s2 = self.fc2.fwd(h)
+        return y, (s1, z, s2)
+
+    def bwd(self, dy, saved):
+        s1, z, s2 = saved
+        dh = self.fc2.bwd(dy, s2)
+        dz = ops.act_bwd(z, dh, ops.ACT_GELU)
+        self.fc1.bwd(dz, s1, need_dx=False)
+
+
+# ======================================================================================================================
+# the whole path
+# ======================================================================================================================
+class VLAEngine:
+    """Prismatic VLM stack + heads.  `get(name)` returns the bf16 device tensor of a reference-named parameter
+    (see weights.py for the state-dict naming)."""
+
+    def __init__(self, cfg: VLAConfig, get, device, *, lora: bool = True, use_proprio: bool = True, head: str = "l1", use_film: bool = False,
+                 has=None):
+        if use_film:
+            raise NotImplementedError("FiLM (config 5) is a later SURVEY section 8 row; not built yet")
+        if head not in ("l1", "diffusion", "none"):
+            raise ValueError(head)
+        ops.check_device(device.index or 0)
+        self.cfg, self.device, self.lora = cfg, device, lora
+        st = self.store = ParamStore(device)
+        # registration order = forward order (the store reverses it into backward order)
+        self.dino = VitTower(st, "vision_backbone.featurizer.", cfg.dino, get, cfg, lora)
+        self.siglip = VitTower(st, "vision_backbone.fused_featurizer.", cfg.siglip, get, cfg, lora)
+        s = cfg.lora_scale
+
+        def L(name):
+            return LoraLinear(st, name, get(name + ".weight"), get(name + ".bias"), get(name + ".lora_A.weight") if lora else None,
+                              get(name + ".lora_B.weight") if lora else None, 1, s)
+
+        self.proj = [L("projector.fc1"), L("projector.fc2"), L("projector.fc3")]
+        self.proprio = MlpProjector(st, get, "proprio_projector.") if use_proprio else None
+        self.noisy = MlpProjector(st, get, "noisy_action_projector.") if head == "diffusion" else None
+        self.embed = get("language_model.model.embed_tokens.weight")
+        self.llm = LlamaStack(st, cfg, get, lora)
+        self.lm_head = get("language_model.lm_head.weight") if (has is None or has("language_model.lm_head.weight")) else None
+        self.head_kind = head
+        self.head = None
+        if head != "none":
+            self.head = ActionHead(st, cfg, get, "action_head.noise_predictor.mlp_resnet." if head == "diffusion" else "action_head.model.")
+        st.finalize()
+        self.refresh_derived()
+
+    # -- bookkeeping -----------------------------------------------------------------------------------------------------
+    def all_linears(self):
+        yield from self.dino.linears()
+        yield from self.siglip.linears()
+        yield from self.proj
+        for m in (self.proprio, self.noisy, self.head):
+            if m is not None:
+                yield from m.linears()
+        yield from self.llm.linears()
+
+    def refresh_derived(self):
+        """Re-derives A^T / B^T / bf16 compute copies from the trainable tensors (after every optimizer step)."""
+        for lin in self.all_linears():
+            lin.refresh_derived()
+
+    def export_trainable(self, kind: str = "data") -> Dict[str, torch.Tensor]:
+        """Every trainable tensor (or its fp32 gradient) keyed by the reference's parameter names: LoRA adapters as
+        `<linear>.lora_A.weight` / `.lora_B.weight` (un-fused per q/k/v, gate/up), components as in their state dicts
+        (prismatic/models/action_heads.py, projectors.py; finetune.py:584-675)."""
+        out: Dict[str, torch.Tensor] = {}
+        for lin in self.all_linears():
+            out.update(lin.export(kind))
+        if self.head is not None:
+            for p in self.head.plain_params():
+                out[p.name] = getattr(p, kind)
+        return out
+
+    # -- forward pieces ----------------------------------------------------------------------------------------------------
+    def vision_fwd(self, pixel_values, train: bool):
+        """pixel_values bf16 [B, 6*I, H, W] -> projected patches bf16 [B, I*Np, D] rows, saved.
+        modeling_prismatic.py:186-227 + :250-262."""
+        cfg = self.cfg
+        B, C = pixel_values.shape[0], pixel_values.shape[1]
+        I = C // 6
+        Np, vd = cfg.dino.n_patches, cfg.vision_dim
+        feats = torch.empty((B, I * Np, vd), dtype=BF16, device=self.device)
+        tower_saved = []
+        for img in range(I):
+            for tower, c0, col0 in ((self.dino, 6 * img, 0), (self.siglip, 6 * img + 3, cfg.dino.dim)):
+                vc = tower.vc
+                T = vc.n_patches + vc.n_prefix
+                tok, sv = tower.fwd(pixel_values, c0, train)
+                ops.copy_rows(tok, feats, B, Np, vc.dim, src_batch_stride=T * vc.dim, src_row0=vc.n_prefix, src_ld=vc.dim,
+                              dst_batch_stride=I * Np * vd, dst_row0=img * Np, dst_ld=vd, dst_col0=col0)
+                tower_saved.append(sv)
+        f2 = feats.view(B * I * Np, vd)
+        z1 = torch.empty((f2.shape[0], 4 * vd), dtype=BF16, device=self.device) if train else None
+        h1, s1 = self.proj[0].fwd(f2, act=ops.ACT_GELU, c_pre=z1)
+        z2 = torch.empty((f2.shape[0], cfg.llm_dim), dtype=BF16, device=self.device) if train else None
+        h2, s2 = self.proj[1].fwd(h1, act=ops.ACT_GELU, c_pre=z2)
+        out, s3 = self.proj[2].fwd(h2)
+        return out.view(B, I * Np, cfg.llm_dim), (tower_saved, s1, z1, s2, z2, s3, B, I)
+
+    def vision_bwd(self, dpatches, saved):
+        """dpatches bf16 [B*I*Np, D] contiguous."""
+        cfg = self.cfg
+        tower_saved, s1, z1, s2, z2, s3, B, I = saved
+        Np, vd = cfg.dino.n_patches, cfg.vision_dim
+        d = self.proj[2].bwd(dpatches, s3)
+        d = self.proj[1].bwd(ops.act_bwd(z2, d, ops.ACT_GELU), s2)
+        dfeat = self.proj[0].bwd(ops.act_bwd(z1, d, ops.ACT_GELU), s1)            # [B*I*Np, vd]
+        k = 0
+        for img in range(I):
+            for tower, col0 in ((self.dino, 0), (self.siglip, cfg.dino.dim)):
+                vc = tower.vc
+                T = vc.n_patches + vc.n_prefix
+                dtok = torch.zeros((B * T, vc.dim), dtype=BF16, device=self.device)
+                # inverse of the feature concat: rows [n_prefix, T) <- columns [col0, col0+dim) of image `img`
+                ops.copy_rows(dfeat[:, col0: col0 + vc.dim], dtok, B, Np, vc.dim, src_batch_stride=I * Np * vd, src_row0=img * Np, src_ld=vd,
+                              dst_batch_stride=T * vc.dim, dst_row0=vc.n_prefix, dst_ld=vc.dim)
+                tower.bwd(dtok, tower_saved[k])
+                k += 1
+
+    # -- the training step pieces -------------------------------------------------------------------------------------------
+    def forward(self, input_ids, attention_mask, pixel_values, labels, proprio=None, noisy_actions=None, timestep_emb=None, train=False):
+        """Multimodal forward (modeling_prismatic.py:571-643 without the discarded lm_head/CE in L1/diffusion mode).
+        Returns dict(hidden [B,S,D], P, action_rows [B,A], saved)."""
+        cfg = self.cfg
+        dev = self.device
+        B, L = input_ids.shape
+        ids = input_ids.to(dev, torch.int64).contiguous()
+        lab = labels.to(dev, torch.int64).contiguous()
+        am = attention_mask.to("cpu").bool()
+        lens = am.sum(1)
+        if not bool((am == (torch.arange(L)[None, :] < lens[:, None])).all()):
+            raise ValueError("attention_mask must be right padding (a prefix of ones per row), as produced by the reference collator")
+        patches, vsaved = self.vision_fwd(pixel_values.to(dev, BF16).contiguous(), train)
+        extra, psaved, nsaved = [], None, None
+        if proprio is not None and self.proprio is not None:
+            pr = torch.zeros(((B + 7) // 8 * 8, cfg.proprio_dim), dtype=BF16, device=dev)
+            pr[:B] = proprio.reshape(B, -1).to(dev, BF16)
+            pf, psaved = self.proprio.fwd(pr, train)
+            extra.append(pf[:B].reshape(B, 1, cfg.llm_dim))
+        if timestep_emb is not None:
+            extra.append(timestep_emb.to(dev, BF16).reshape(B, 1, cfg.llm_dim))
+        if extra:
+            # token concat along the sequence dim (pure data movement)
+            allp = torch.empty((B, patches.shape[1] + len(extra), cfg.llm_dim), dtype=BF16, device=dev)
+            allp[:, : patches.shape[1]] = patches
+            for j, e in enumerate(extra):
+                allp[:, patches.shape[1] + j] = e[:, 0]
+        else:
+            allp = patches
+        P = allp.shape[1]
+        A = cfg.num_action_tokens
+        noisy_feats = None
+        if noisy_actions is not None:
+            na = noisy_actions.reshape(B * A, 1).to(dev, BF16)
+            nf, nsaved = self.noisy.fwd(na, train)
+            noisy_feats = nf.view(B, A, cfg.llm_dim)
+        mm, action_rows = ops.assemble_multimodal(ids, lab, self.embed, allp.contiguous(), A=A, noisy=noisy_feats, action_dim=cfg.action_dim)
+        S = P + L
+        kv_len = (lens + P).to(torch.int32).to(dev)
+        hidden, lsaved = self.llm.fwd(mm.view(B * S, cfg.llm_dim), B, S, kv_len, train)
+        saved = (vsaved, psaved, nsaved, lsaved, B, S, P, patches.shape[1]) if train else None
+        return dict(hidden=hidden.view(B, S, cfg.llm_dim), P=P, action_rows=action_rows, saved=saved)
+
+    def gather_action_hidden(self, hidden, action_rows):
+        """Rows of hidden that predict the action slots: the hidden state at token i-1 predicts token i
+        (finetune.py:385-394: text_hidden = last_hidden[:, P:-1] indexed with masks built from labels[:, 1:];
+        modeling_prismatic.py:915-920).  `action_rows` (flattened (b, s) row of slot - 1) comes from the assembly kernel."""
+        B, S, D = hidden.shape
+        idx = action_rows.reshape(-1)
+        return ops.gather_rows(hidden.view(B * S, D), idx, D), idx
+
+    def train_step_fwd_bwd(self, batch: dict, loss_scale: float = 1.0):
+        """One run_forward_pass (finetune.py:280-451, L1 branch) + backward.  Gradients accumulate in the flat buffers.
+        Returns (loss_sum fp32[1] device, count)."""
+        cfg = self.cfg
+        out = self.forward(batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["labels"], proprio=batch.get("proprio"),
+                           train=True)
+        hidden, P = out["hidden"], out["P"]
+        B, S, D = hidden.shape
+        ah, idx = self.gather_action_hidden(hidden, out["action_rows"])
+        target = batch["actions"].to(self.device, BF16).reshape(B * cfg.chunk, cfg.action_dim).contiguous()
+        pred, loss_sum, hsaved = self.head.fwd(ah, target=target, mse=False, train=True)
+        # ---- backward ----
+        dah = self.head.bwd(hsaved, dloss=loss_scale)
+        dhidden = torch.zeros((B * S, D), dtype=BF16, device=self.device)
+        ops.gather_rows(dah, idx, D, dst=dhidden, scatter_add=True)
+        vsaved, psaved, nsaved, lsaved, _, _, _, n_vis = out["saved"]
+        dmm = self.llm.bwd(dhidden, lsaved).view(B, S, D)
+        if psaved is not None:
+            dpr = torch.zeros(((B + 7) // 8 * 8, D), dtype=BF16, device=self.device)
+            dpr[:B] = dmm[:, 1 + n_vis]
+            self.proprio.bwd(dpr, psaved)
+        dpatches = dmm[:, 1: 1 + n_vis].contiguous().view(B * n_vis, D)
+        self.vision_bwd(dpatches, vsaved)
+        return loss_sum, pred.numel(), pred

@@ -34,7 +34,7 @@ def check_device(index: int = 0) -> None:
 
 # ----------------------------------------------------------------------------------------------------------------------
 def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=None, c_pre=None, a2=None, b2=None,
-         k2_group_n=0, film=None, split_k=1, tile=0):
+         k2_group_n=0, film=None, split_k=1, tile=0, alpha=1.0):
     """out[M,N] = epilogue(a[M,K] @ b[N,K]^T (+ a2[M,G*K2] @ b2[N,K2]^T)); all bf16 2-D, last dim contiguous."""
     _chk(a, name="a"); _chk(b, name="b")
     M, K = a.shape
@@ -67,7 +67,7 @@ def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=Non
         gamma, beta, rows = film
         assert gamma.shape[-1] == N and gamma.is_contiguous() and beta.is_contiguous()
         g.film_gamma, g.film_beta, g.film_rows = gamma.data_ptr(), beta.data_ptr(), rows
-    g.M, g.N, g.K, g.act, g.split_k, g.tile = M, N, K, act, split_k, tile
+    g.M, g.N, g.K, g.act, g.split_k, g.tile, g.alpha = M, N, K, act, split_k, tile, alpha
     ws = None
     if split_k > 1:
         ws = torch.empty((split_k, M, N), dtype=torch.float32, device=a.device)
@@ -286,7 +286,8 @@ def masked_mean(x, row_mask, B, L, dim):
 
 
 def assemble_multimodal(ids, labels, table, patches, *, A, noisy=None, ignore_index=-100, action_token_begin=31743, action_dim=7):
-    """ids/labels int64 [B,L]; table bf16 [V,D]; patches bf16 [B,P,D] -> (out [B,P+L,D], action_pos int32 [B,A])."""
+    """ids/labels int64 [B,L]; table bf16 [V,D]; patches bf16 [B,P,D] -> (out [B,P+L,D], action_rows int32 [B,A]:
+    flattened row of the hidden state that predicts each action slot)."""
     B, L = ids.shape
     P, D = patches.shape[1], patches.shape[2]
     out = torch.empty((B, P + L, D), dtype=BF16, device=table.device)

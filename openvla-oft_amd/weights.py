@@ -1,0 +1,104 @@
+"""Weights in the reference's parameter naming -> device tensors for the engine.
+
+State-dict names follow the reference's HF checkpoint layout (vla-scripts/extern/convert_openvla_weights_to_hf.py:73-115):
+  vision_backbone.featurizer.*        DINOv2 (timm names; LayerScale as `ls{1,2}.scale_factor`, modeling_prismatic.py:60-64)
+  vision_backbone.fused_featurizer.*  SigLIP
+  projector.fc{1,2,3}.*               language_model.model.* / language_model.lm_head.weight
+plus the fine-tune components as saved by finetune.py:584-675: action_head.model.* (or action_head.noise_predictor.mlp_resnet.*),
+proprio_projector.fc{1,2}.*, noisy_action_projector.fc{1,2}.*, and LoRA adapters as <linear>.lora_A.weight / .lora_B.weight.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict
+
+import torch
+
+from .config import VLAConfig
+
+BF16 = torch.bfloat16
+
+
+def make_getter(sd: Dict[str, torch.Tensor], device) -> tuple[Callable[[str], torch.Tensor], Callable[[str], bool]]:
+    def get(name: str) -> torch.Tensor:
+        if name not in sd:
+            raise KeyError(f"state dict has no parameter `{name}`")
+        return sd[name].detach().to(device=device, dtype=BF16).contiguous()
+
+    return get, (lambda name: name in sd)
+
+
+def random_state_dict(cfg: VLAConfig, device, seed: int = 0, *, lora: bool = True, diffusion: bool = False, lm_head: bool = True,
+                      dtype=BF16) -> Dict[str, torch.Tensor]:
+    """Seeded random weights of the configured architecture, generated ON DEVICE (no checkpoint exists offline; SURVEY.md
+    section 8d config 3: N(0, 0.02)-style init, norm weights ~1, LayerScale 0.1, LoRA A ~ N(0, 1/r), B perturbed from 0)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def normal(*shape, s=0.02):
+        return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * s).to(dtype)
+
+    def around_one(n, s=0.1):
+        return (1.0 + s * torch.randn(n, generator=g, device=device)).to(dtype)
+
+    def lin(name, out_f, in_f, bias=True, with_lora=lora, s=0.02):
+        sd[name + ".weight"] = normal(out_f, in_f, s=s)
+        if bias:
+            sd[name + ".bias"] = normal(out_f, s=0.02)
+        if with_lora:
+            sd[name + ".lora_A.weight"] = normal(cfg.lora_rank, in_f, s=1.0 / cfg.lora_rank)
+            sd[name + ".lora_B.weight"] = normal(out_f, cfg.lora_rank, s=0.01)
+
+    def ln(name, dim):
+        sd[name + ".weight"] = around_one(dim)
+        sd[name + ".bias"] = normal(dim, s=0.05)
+
+    for prefix, vc in (("vision_backbone.featurizer.", cfg.dino), ("vision_backbone.fused_featurizer.", cfg.siglip)):
+        sd[prefix + "patch_embed.proj.weight"] = normal(vc.dim, 3, vc.patch, vc.patch, s=0.05)
+        sd[prefix + "patch_embed.proj.bias"] = normal(vc.dim)
+        sd[prefix + "pos_embed"] = normal(1, vc.n_patches, vc.dim, s=0.1)
+        if vc.n_prefix > 0:
+            sd[prefix + "cls_token"] = normal(1, 1, vc.dim, s=0.1)
+            if vc.n_prefix > 1:
+                sd[prefix + "reg_token"] = normal(1, vc.n_prefix - 1, vc.dim, s=0.1)
+        for i in range(vc.depth - 1):  # the last block's output is never used on this path
+            p = f"{prefix}blocks.{i}."
+            ln(p + "norm1", vc.dim)
+            lin(p + "attn.qkv", 3 * vc.dim, vc.dim, s=0.03)
+            lin(p + "attn.proj", vc.dim, vc.dim, s=0.03)
+            ln(p + "norm2", vc.dim)
+            lin(p + "mlp.fc1", vc.mlp_hidden, vc.dim, s=0.03)
+            lin(p + "mlp.fc2", vc.dim, vc.mlp_hidden, s=0.03)
+            if vc.layerscale:
+                sd[p + "ls1.scale_factor"] = (0.1 + 0.02 * torch.randn(vc.dim, generator=g, device=device)).to(dtype)
+                sd[p + "ls2.scale_factor"] = (0.1 + 0.02 * torch.randn(vc.dim, generator=g, device=device)).to(dtype)
+    vis, D = cfg.vision_dim, cfg.llm_dim
+    lin("projector.fc1", 4 * vis, vis)
+    lin("projector.fc2", D, 4 * vis)
+    lin("projector.fc3", D, D)
+    sd["language_model.model.embed_tokens.weight"] = normal(cfg.vocab, D, s=0.5)
+    for i in range(cfg.llm_layers):
+        p = f"language_model.model.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            lin(p + "self_attn." + n, D, D, bias=False)
+        lin(p + "mlp.gate_proj", cfg.llm_ff, D, bias=False)
+        lin(p + "mlp.up_proj", cfg.llm_ff, D, bias=False)
+        lin(p + "mlp.down_proj", D, cfg.llm_ff, bias=False)
+        sd[p + "input_layernorm.weight"] = around_one(D)
+        sd[p + "post_attention_layernorm.weight"] = around_one(D)
+    sd["language_model.model.norm.weight"] = around_one(D)
+    if lm_head:
+        lin("language_model.lm_head", cfg.vocab, D, bias=False, with_lora=False, s=0.05)
+    lin("proprio_projector.fc1", D, cfg.proprio_dim, with_lora=False, s=0.3)
+    lin("proprio_projector.fc2", D, D, with_lora=False, s=0.02)
+    hp = "action_head.noise_predictor.mlp_resnet." if diffusion else "action_head.model."
+    ln(hp + "layer_norm1", D * cfg.action_dim)
+    lin(hp + "fc1", D, D * cfg.action_dim, with_lora=False, s=0.01)
+    for b in range(2):
+        ln(f"{hp}mlp_resnet_blocks.{b}.ffn.0", D)
+        lin(f"{hp}mlp_resnet_blocks.{b}.ffn.1", D, D, with_lora=False, s=0.02)
+    ln(hp + "layer_norm2", D)
+    lin(hp + "fc2", cfg.action_dim, D, with_lora=False, s=0.05)
+    if diffusion:
+        lin("noisy_action_projector.fc1", D, 1, with_lora=False, s=0.5)
+        lin("noisy_action_projector.fc2", D, D, with_lora=False, s=0.02)
+    return sd

@@ -368,7 +368,7 @@ def test_assemble_and_gather(ops, dev):
         out, apos = ops.assemble_multimodal(ids, labels, table, patches, A=A, noisy=noisy if use_noisy else None)
         assert torch.equal(out, ref), f"assemble (noisy={use_noisy})"
         for b_ in range(B):
-            assert torch.equal(apos[b_].long(), torch.where(amask[b_])[0]), "action positions"
+            assert torch.equal(apos[b_].long(), b_ * (P + L) + P + torch.where(amask[b_])[0] - 1), "predicting rows of the action slots"
     src = rnd(50, D, dev=dev)
     idx = torch.tensor([3, 49, 0, 7], dtype=torch.int32, device=dev)
     g = ops.gather_rows(src, idx, D)
