@@ -193,9 +193,11 @@ int ovla_colscale_bf16(const ovla_colscale_args* a, void* stream); /* out[m,n] =
 /* ------------------------------------------------------------------------------------------------------------------
  * Vision front end.
  * im2col for the 14x14/stride-14 patch embedding (timm PatchEmbed Conv2d as GEMM): pixel_values bf16 NCHW
- * [B, C_total, H, W], channels [c0, c0+3) -> rows [B*gh*gw, ldo] with K = 3*p*p real columns (c, py, px) and zero pad.
+ * [B, C_total, H, W]; image `img` (0..n_img-1) of a batch row uses channels [c0 + img*img_cstride, +3)
+ * (modeling_prismatic.py:210-224: 6 channels per image, DINOv2 first, SigLIP second) -> rows [(B*n_img)*gh*gw, ldo] with
+ * K = 3*p*p real columns (c, py, px) and zero pad.  n_img == 0 means 1.
  */
-typedef struct { const void* pixels; void* out; int64_t ldo; int32_t B, C_total, c0, H, W, patch; } ovla_im2col_args;
+typedef struct { const void* pixels; void* out; int64_t ldo; int32_t B, C_total, c0, H, W, patch, n_img, img_cstride; } ovla_im2col_args;
 int ovla_im2col(const ovla_im2col_args* a, void* stream);
 
 /* tokens[b, pre + i, :] = patches[b, i, :] + pos[i, :] ;  tokens[b, j, :] = prefix[j, :]  (cls / register tokens)

@@ -256,11 +256,12 @@ __global__ __launch_bounds__(256) void colscale_kernel(const bf16_bits* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// im2col for patch embedding: out[(b, gy, gx), (c, py, px)], K padded with zeros up to ldo.
+// im2col for patch embedding: out[((b, img), gy, gx), (c, py, px)], K padded with zeros up to ldo.  Image `img` of
+// batch row b lives in channels [c0 + img*img_cstride, +3) of the channel-stacked pixel tensor.
 __global__ __launch_bounds__(256) void im2col_kernel(const bf16_bits* __restrict__ px, bf16_bits* __restrict__ out, int64_t ldo,
-                                                     int B, int C_total, int c0, int H, int W, int patch) {
+                                                     int B, int C_total, int c0, int H, int W, int patch, int n_img, int img_cstride) {
   const int gh = H / patch, gw = W / patch;
-  const int64_t total = (int64_t)B * gh * gw * ldo;
+  const int64_t total = (int64_t)B * n_img * gh * gw * ldo;
   const int kreal = 3 * patch * patch;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int k = (int)(idx % ldo);
@@ -269,8 +270,10 @@ __global__ __launch_bounds__(256) void im2col_kernel(const bf16_bits* __restrict
     if (k < kreal) {
       const int c = k / (patch * patch), py = (k / patch) % patch, pxx = k % patch;
       const int gx = (int)(r % gw), gy = (int)((r / gw) % gh);
-      const int64_t b = r / ((int64_t)gw * gh);
-      v = px[((b * C_total + c0 + c) * H + gy * patch + py) * (int64_t)W + gx * patch + pxx];
+      const int64_t bi = r / ((int64_t)gw * gh);
+      const int64_t b = bi / n_img;
+      const int img = (int)(bi % n_img);
+      v = px[((b * C_total + c0 + img * img_cstride + c) * H + gy * patch + py) * (int64_t)W + gx * patch + pxx];
     }
     out[idx] = v;
   }
@@ -553,10 +556,11 @@ extern "C" int ovla_im2col(const ovla_im2col_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   OVLA_REQUIRE(a && a->pixels && a->out, "ovla_im2col: null pointer");
   OVLA_REQUIRE(a->B > 0 && a->patch > 0 && a->H % a->patch == 0 && a->W % a->patch == 0, "ovla_im2col: image %dx%d not divisible by patch %d", a->H, a->W, a->patch);
-  OVLA_REQUIRE(a->c0 >= 0 && a->c0 + 3 <= a->C_total && a->ldo >= 3 * a->patch * a->patch, "ovla_im2col: channel range / ldo");
-  const int64_t total = (int64_t)a->B * (a->H / a->patch) * (a->W / a->patch) * a->ldo;
+  const int n_img = a->n_img > 0 ? a->n_img : 1;
+  OVLA_REQUIRE(a->c0 >= 0 && a->c0 + (n_img - 1) * a->img_cstride + 3 <= a->C_total && a->ldo >= 3 * a->patch * a->patch, "ovla_im2col: channel range / ldo");
+  const int64_t total = (int64_t)a->B * n_img * (a->H / a->patch) * (a->W / a->patch) * a->ldo;
   hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16_bits*)a->pixels, (bf16_bits*)a->out, a->ldo,
-                     a->B, a->C_total, a->c0, a->H, a->W, a->patch);
+                     a->B, a->C_total, a->c0, a->H, a->W, a->patch, n_img, a->img_cstride);
   OVLA_CHECK_LAUNCH("ovla_im2col");
   return OVLA_OK;
 }

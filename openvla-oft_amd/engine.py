@@ -278,11 +278,12 @@ class VitTower:
         for b in self.blocks:
             yield from (b["qkv"], b["proj"], b["fc1"], b["fc2"])
 
-    def fwd(self, pixels, c0: int, train: bool):
-        """pixels bf16 [B, C, H, W]; channels [c0, c0+3).  Returns (tokens [B*T, dim] after block depth-2, saved)."""
+    def fwd(self, pixels, c0: int, n_img: int, train: bool):
+        """pixels bf16 [B, 6*n_img, H, W]; image i uses channels [c0 + 6 i, +3).  All images go through the tower as one
+        batch of B*n_img (ordered (b, img)).  Returns (tokens [B*n_img*T, dim] after block depth-2, saved)."""
         vc = self.vc
-        B = pixels.shape[0]
-        cols = ops.im2col(pixels, c0, vc.patch, vc.patch_k)
+        B = pixels.shape[0] * n_img
+        cols = ops.im2col(pixels, c0, vc.patch, vc.patch_k, n_img=n_img, img_cstride=6)
         patches = ops.gemm(cols, self.patch_w, bias=self.patch_b)
         x = ops.vit_embed(patches, self.pos, self.prefix_tokens, B, vc.n_patches, vc.dim)
         T = vc.n_patches + vc.n_prefix
@@ -582,16 +583,16 @@ class VLAEngine:
         B, C = pixel_values.shape[0], pixel_values.shape[1]
         I = C // 6
         Np, vd = cfg.dino.n_patches, cfg.vision_dim
-        feats = torch.empty((B, I * Np, vd), dtype=BF16, device=self.device)
+        feats = torch.empty((B, I * Np, vd), dtype=BF16, device=self.device)   # == [(B*I), Np, vd]: (b, img) is the tower batch
         tower_saved = []
-        for img in range(I):
-            for tower, c0, col0 in ((self.dino, 6 * img, 0), (self.siglip, 6 * img + 3, cfg.dino.dim)):
-                vc = tower.vc
-                T = vc.n_patches + vc.n_prefix
-                tok, sv = tower.fwd(pixel_values, c0, train)
-                ops.copy_rows(tok, feats, B, Np, vc.dim, src_batch_stride=T * vc.dim, src_row0=vc.n_prefix, src_ld=vc.dim,
-                              dst_batch_stride=I * Np * vd, dst_row0=img * Np, dst_ld=vd, dst_col0=col0)
-                tower_saved.append(sv)
+        for tower, c0, col0 in ((self.dino, 0, 0), (self.siglip, 3, cfg.dino.dim)):
+            vc = tower.vc
+            T = vc.n_patches + vc.n_prefix
+            tok, sv = tower.fwd(pixel_values, c0, I, train)
+            # drop prefix tokens, concat features on dim 2 and images on dim 1 (modeling_prismatic.py:221-227)
+            ops.copy_rows(tok, feats, B * I, Np, vc.dim, src_batch_stride=T * vc.dim, src_row0=vc.n_prefix, src_ld=vc.dim,
+                          dst_batch_stride=Np * vd, dst_row0=0, dst_ld=vd, dst_col0=col0)
+            tower_saved.append(sv)
         f2 = feats.view(B * I * Np, vd)
         z1 = torch.empty((f2.shape[0], 4 * vd), dtype=BF16, device=self.device) if train else None
         h1, s1 = self.proj[0].fwd(f2, act=ops.ACT_GELU, c_pre=z1)
@@ -608,17 +609,14 @@ class VLAEngine:
         d = self.proj[2].bwd(dpatches, s3)
         d = self.proj[1].bwd(ops.act_bwd(z2, d, ops.ACT_GELU), s2)
         dfeat = self.proj[0].bwd(ops.act_bwd(z1, d, ops.ACT_GELU), s1)            # [B*I*Np, vd]
-        k = 0
-        for img in range(I):
-            for tower, col0 in ((self.dino, 0), (self.siglip, cfg.dino.dim)):
-                vc = tower.vc
-                T = vc.n_patches + vc.n_prefix
-                dtok = torch.zeros((B * T, vc.dim), dtype=BF16, device=self.device)
-                # inverse of the feature concat: rows [n_prefix, T) <- columns [col0, col0+dim) of image `img`
-                ops.copy_rows(dfeat[:, col0: col0 + vc.dim], dtok, B, Np, vc.dim, src_batch_stride=I * Np * vd, src_row0=img * Np, src_ld=vd,
-                              dst_batch_stride=T * vc.dim, dst_row0=vc.n_prefix, dst_ld=vc.dim)
-                tower.bwd(dtok, tower_saved[k])
-                k += 1
+        for k, (tower, col0) in enumerate(((self.dino, 0), (self.siglip, cfg.dino.dim))):
+            vc = tower.vc
+            T = vc.n_patches + vc.n_prefix
+            dtok = torch.zeros((B * I * T, vc.dim), dtype=BF16, device=self.device)
+            # inverse of the feature concat: rows [n_prefix, T) of tower batch (b, img) <- columns [col0, col0+dim)
+            ops.copy_rows(dfeat[:, col0: col0 + vc.dim], dtok, B * I, Np, vc.dim, src_batch_stride=Np * vd, src_row0=0, src_ld=vd,
+                          dst_batch_stride=T * vc.dim, dst_row0=vc.n_prefix, dst_ld=vc.dim)
+            tower.bwd(dtok, tower_saved[k])
 
     # -- the training step pieces -------------------------------------------------------------------------------------------
     def forward(self, input_ids, attention_mask, pixel_values, labels, proprio=None, noisy_actions=None, timestep_emb=None, train=False):

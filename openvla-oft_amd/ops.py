@@ -12,6 +12,25 @@ from ._lib import STRUCTS
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU, ACT_GELU_TANH = 0, 1, 2, 3, 4
 BF16 = torch.bfloat16
 
+# bench.py sets this to a list to time individual launches with HIP events on the launch stream:
+# entries are (kernel_family, start_event, end_event, algorithmic_flops)
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, family, flops):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append((family, e0, e1, flops))
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -72,7 +91,9 @@ def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=Non
     if split_k > 1:
         ws = torch.empty((split_k, M, N), dtype=torch.float32, device=a.device)
         g.workspace = ws.data_ptr()
+    e0 = _prof_begin()
     _lib.call("ovla_gemm_bf16", g, _stream())
+    _prof_end(e0, "gemm_nt", 2.0 * M * N * (K + (b2.shape[1] if b2 is not None else 0)))
     return out
 
 
@@ -93,7 +114,9 @@ def gemm_tn(x, y, *, out=None, alpha=1.0, accumulate=True, out_dtype=torch.float
         g.out_mode = 0
     else:
         g.out_mode = 1 if out.dtype == torch.float32 else 2
+    e0 = _prof_begin()
     _lib.call("ovla_gemm_tn_bf16", g, _stream())
+    _prof_end(e0, "gemm_tn", 2.0 * M * P * Q)
     return out
 
 
@@ -120,7 +143,9 @@ def attn_fwd(q, k, v, B, S, H, hd, *, kv_len=None, causal=False, scale=None, out
     g.O, g.o_stride, g.lse, g.kv_len = out.data_ptr(), out.stride(0), lse.data_ptr(), _p(kv_len)
     g.B, g.H, g.S, g.head_dim, g.causal = B, H, S, hd, int(causal)
     g.scale = float(scale if scale is not None else hd ** -0.5)
+    e0 = _prof_begin()
     _lib.call("ovla_attn_fwd", g, _stream())
+    _prof_end(e0, "attn_fwd", 4.0 * B * H * S * S * hd * (0.5 if causal else 1.0))
     return out, lse
 
 
@@ -144,7 +169,9 @@ def attn_bwd(q, k, v, o, do, lse, B, S, H, hd, *, kv_len=None, causal=False, sca
     g.kv_len = _p(kv_len)
     g.B, g.H, g.S, g.head_dim, g.causal = B, H, S, hd, int(causal)
     g.scale = float(scale if scale is not None else hd ** -0.5)
+    e0 = _prof_begin()
     _lib.call("ovla_attn_bwd", g, _stream())
+    _prof_end(e0, "attn_bwd", 10.0 * B * H * S * S * hd * (0.5 if causal else 1.0))
     return dq, dk, dv
 
 
@@ -246,13 +273,14 @@ def colscale(x, scale, out=None):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-def im2col(pixels, c0, patch, k_padded):
+def im2col(pixels, c0, patch, k_padded, n_img=1, img_cstride=6):
     _chk(pixels)
     B, C, H, W = pixels.shape
     assert pixels.is_contiguous()
-    out = torch.empty((B * (H // patch) * (W // patch), k_padded), dtype=BF16, device=pixels.device)
+    out = torch.empty((B * n_img * (H // patch) * (W // patch), k_padded), dtype=BF16, device=pixels.device)
     g = STRUCTS["ovla_im2col_args"]()
     g.pixels, g.out, g.ldo, g.B, g.C_total, g.c0, g.H, g.W, g.patch = pixels.data_ptr(), out.data_ptr(), k_padded, B, C, c0, H, W, patch
+    g.n_img, g.img_cstride = n_img, img_cstride
     _lib.call("ovla_im2col", g, _stream())
     return out
 

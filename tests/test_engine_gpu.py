@@ -71,37 +71,42 @@ def test_forward_matches_oracle(setup):
 
 
 def test_backward_matches_oracle_autograd(setup):
-    eng, ocfg, sd, batch = setup["eng"], setup["ocfg"], setup["sd"], setup["batch"]
+    eng, ocfg, sd, batch = setup["eng"], setup["ocfg"], setup["sd"], dict(setup["batch"])
     names = set(eng.export_trainable("data"))
     sdg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
     assert all(n in sdg for n in names), sorted(n for n in names if n not in sdg)[:5]
     o = vo.Oracle(ocfg, sdg, mode="fp32")
+    # d|x|/dx = sign(x) is discontinuous: keep every residual at least 0.25 away from zero so that bf16-level
+    # differences in the prediction cannot flip a sign and the comparison measures the backward arithmetic only.
+    # (the action values only enter the forward through the loss: their token embeddings are zeroed, :620-621)
+    with torch.no_grad():
+        _, p0, _ = o.train_forward(batch)
+    g = torch.Generator().manual_seed(7)
+    off = (0.25 + 0.5 * torch.rand(p0.shape, generator=g)) * torch.where(torch.rand(p0.shape, generator=g) < 0.5, -1.0, 1.0)
+    batch["actions"] = (p0 + off).to(BF).float()
     loss, _, _ = o.train_forward(batch)
     loss.backward()
     eng.store.zero_grad()
     loss_sum, count, _ = eng.train_step_fwd_bwd(batch)
-    assert abs(loss_sum.item() / count - loss.item()) < 3e-2 * max(1.0, abs(loss.item()))
+    assert abs(loss_sum.item() / count - loss.item()) < 2e-2 * max(1.0, abs(loss.item()))
     grads = eng.export_trainable("grad")
-    worst = []
+    worst, cos = [], []
     for n in sorted(names):
         ref = sdg[n].grad
         assert ref is not None, n
         got = grads[n].float().cpu()
         assert got.shape == ref.shape, n
+        assert torch.isfinite(got).all(), n
         worst.append((rel(got, ref) if ref.abs().max() > 1e-7 else got.abs().max().item(), n))
+        if ref.norm() > 1e-6:
+            cos.append((torch.dot(got.flatten(), ref.flatten()) / (got.norm() * ref.norm() + 1e-20)).item())
     worst.sort(reverse=True)
-    print("worst gradient mismatches:", [(f"{e:.2e}", n) for e, n in worst[:8]])
-    # bf16 forward + bf16 gradient signal through a 2-layer LLM / 2-block ViTs: sign(pred - target) flips on near-zero
-    # residuals are the dominant effect, so the bound is loose on max-normalised error but tight on direction
-    bad = [(e, n) for e, n in worst if e > 0.15]
-    assert not bad, bad[:10]
-    cos = []
-    for n in names:
-        a, b = grads[n].float().cpu().flatten(), sdg[n].grad.flatten()
-        if b.norm() > 1e-6:
-            cos.append((torch.dot(a, b) / (a.norm() * b.norm() + 1e-20)).item())
-    print(f"gradient cosine: min {min(cos):.4f} mean {np.mean(cos):.4f}")
-    assert min(cos) > 0.98
+    print("worst gradient mismatches:", [(f"{e:.2e}", n) for e, n in worst[:6]])
+    print(f"gradient cosine: min {min(cos):.5f} mean {np.mean(cos):.5f}")
+    # bf16 activations and bf16 gradient signal (8 significant bits) through 2 LLM layers and 2x2 ViT blocks:
+    # max-normalised elementwise error below 6 %, direction within 0.2 %
+    assert worst[0][0] < 6e-2, worst[:10]
+    assert min(cos) > 0.998
 
 
 def test_optimizer_step_moves_toward_lower_loss(setup):
