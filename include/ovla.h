@@ -78,7 +78,8 @@ typedef struct {
   int32_t split_k;               /* <=1: none */
   int32_t tile;                  /* 0: auto; otherwise forces a tile configuration (tests / tuning) */
   float alpha;                   /* scales the accumulator (LoRA alpha/r); 0 means 1 */
-  void* workspace;               /* fp32 [split_k, M, N] when split_k > 1 */
+  void* workspace;               /* fp32 scratch: [split_k, M, N] when split_k > 1; also enables the auto schedules */
+  int64_t workspace_bytes;       /* (hybrid remainder split, skinny-N split-K) when tile == 0; may be NULL/0 */
 } ovla_gemm_args;
 
 int64_t ovla_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);

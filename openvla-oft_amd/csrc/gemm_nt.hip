@@ -36,6 +36,7 @@ struct GemmParams {
   float alpha;
   float* ws;
   int tiles_m, tiles_n, T1, T2;
+  int full_tiles, rem_tiles, rem_splits;  // hybrid schedule: tiles >= full_tiles are split rem_splits ways along K
 };
 
 // Stage ROWS x 64 bf16 of a row-major [rows, ld] matrix into an LDS tile (swizzled 128-byte rows) with LDS-DMA.
@@ -122,15 +123,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
 
-  // ---- block -> (split, tile_m, tile_n): XCD-contiguous bands, then 8-deep row groups ------------------------
+  // ---- block -> work unit ------------------------------------------------------------------------------------
+  // Plain / split-K launch: blocks [0, tiles*splits) ; block ids are remapped so each XCD (private L2) owns a contiguous
+  // band of tiles.  Hybrid launch (rem_tiles > 0): blocks [0, full_tiles) are whole tiles (whole rounds of the chip);
+  // the remaining tiles -- a partial round that would leave most CUs idle -- are split rem_splits ways along K, one block
+  // per (tile, K part), partial sums going to the fp32 workspace for gemm_hybrid_reduce_kernel.
   int bid = blockIdx.x;
-  {
-    const int nblk = gridDim.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
   const int tiles_mn = p.tiles_m * p.tiles_n;
-  const int split = bid / tiles_mn;
-  const int t_mn = bid - split * tiles_mn;
+  const int remap_n = p.rem_tiles > 0 ? p.full_tiles : (int)gridDim.x;
+  int split = 0, t_mn, rem_unit = -1;
+  if (bid < remap_n) {
+    const int xcd = bid & 7, q = remap_n >> 3, r = remap_n & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    split = bid / tiles_mn;
+    t_mn = bid - split * tiles_mn;
+  } else {
+    rem_unit = bid - p.full_tiles;
+    t_mn = p.full_tiles + rem_unit / p.rem_splits;
+    split = rem_unit % p.rem_splits;
+  }
   constexpr int GROUP = 8;
   const int group_sz = GROUP * p.tiles_n;
   const int gid = t_mn / group_sz;
@@ -143,8 +154,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
 
   const int T = p.T1 + p.T2;
   int t_begin = 0, t_end = T;
-  if (p.split_k > 1) {
-    const int chunk = (T + p.split_k - 1) / p.split_k;
+  const int nsplit = rem_unit >= 0 ? p.rem_splits : p.split_k;
+  if (nsplit > 1) {
+    const int chunk = (T + nsplit - 1) / nsplit;
     t_begin = split * chunk;
     t_end = t_begin + chunk < T ? t_begin + chunk : T;
   }
@@ -196,6 +208,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // MFMA layout (operands swapped): lane owns C[m][n..n+3] with m = tile row (lane&15), n = 4*(lane>>4).
+  if (rem_unit >= 0) {  // hybrid remainder unit: tile-local fp32 slab [rem_unit][BM][BN]
+    float* slab = p.ws + (int64_t)rem_unit * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        *reinterpret_cast<f32x4*>(slab + (wm * WTM + i * 16 + (lane & 15)) * BN + wn * WTN + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+    return;
+  }
   if (p.split_k > 1) {  // raw fp32 partials; the reduce kernel applies the epilogue
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -235,6 +256,191 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   }
 }
 
+// =====================================================================================================================
+// Deep-pipelined variant (large tiles, ~1 workgroup per CU).
+//   * BK = 32 stages in a STAGES-deep LDS ring: STAGES-1 stages of LDS-DMA stay in flight across the per-stage barrier
+//     (counted s_waitcnt vmcnt, raw s_barrier -- __syncthreads() would drain the DMA queue, cdna_hip_programming.md
+//     "Pipelining across barriers"), so HBM/L2 latency is covered by (STAGES-1) x one stage of MFMA time;
+//   * 64-byte LDS rows, 16-byte chunk index XOR g[(row>>2)&3], g = {0,3,2,1}: conflict-free ds_read_b128 fragments;
+//   * the LoRA rank-32 K-extension is exactly one extra stage.
+constexpr int PK = 32;
+
+template <int ROWS, int NW>
+OVLA_DEV void stage_tile32(const bf16_bits* __restrict__ G, int64_t ld, int row0, int row_last, int k0, int K,
+                           bf16_bits* lds_tile, int wave, int lane) {
+  constexpr int PER_WAVE = ROWS / 16 / NW;
+  static_assert(PER_WAVE * 16 * NW == ROWS, "tile rows must split evenly over the waves");
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int rbase = (wave * PER_WAVE + i) * 16;   // one instruction writes rows rbase..rbase+15 (64 B each)
+    const int r = rbase + (lane >> 2);
+    const int c = (lane & 3) ^ ((4 - ((r >> 2) & 3)) & 3);
+    const int kk = k0 + c * 8;
+    int gr = row0 + r;
+    gr = gr < row_last ? gr : row_last;
+    const bf16_bits* src = (kk < K) ? (G + (int64_t)gr * ld + kk) : g_ovla_zero_chunk;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds_tile + rbase * PK), 16, 0, 0);
+  }
+}
+
+OVLA_DEV bf16x8_bits lds_frag32(const bf16_bits* tile, int row, int chunk) {
+  const int phys = chunk ^ ((4 - ((row >> 2) & 3)) & 3);
+  return *reinterpret_cast<const bf16x8_bits*>(tile + row * PK + phys * 8);
+}
+
+template <int N>
+OVLA_DEV void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else static_assert(N == 0, "add the vmcnt literal");
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_pipe_kernel(const GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MT = WTM / 16, NT = WTN / 16;
+  constexpr int STAGE_ELEMS = (BM + BN) * PK;
+  constexpr int G = (BM + BN) / 16 / NW;   // LDS-DMA instructions per wave per stage
+  constexpr int D = STAGES - 1;            // stages in flight
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_bits* smem = reinterpret_cast<bf16_bits*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  int bid = blockIdx.x;
+  {
+    const int nblk = gridDim.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tiles_mn = p.tiles_m * p.tiles_n;
+  const int split = bid / tiles_mn;
+  const int t_mn = bid - split * tiles_mn;
+  constexpr int GROUP = 4;
+  const int group_sz = GROUP * p.tiles_n;
+  const int gid = t_mn / group_sz;
+  const int first_m = gid * GROUP;
+  const int gm = (p.tiles_m - first_m) < GROUP ? (p.tiles_m - first_m) : GROUP;
+  const int in_group = t_mn - gid * group_sz;
+  const int tm = first_m + in_group % gm;
+  const int tn = in_group / gm;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int T1 = (p.K + PK - 1) / PK, T2 = p.K2 > 0 ? (p.K2 + PK - 1) / PK : 0;
+  const int T = T1 + T2;
+  int t_begin = 0, t_end = T;
+  if (p.split_k > 1) {
+    const int chunk = (T + p.split_k - 1) / p.split_k;
+    t_begin = split * chunk;
+    t_end = t_begin + chunk < T ? t_begin + chunk : T;
+  }
+  const int a2_col0 = p.k2_group_n > 0 ? (n0 / p.k2_group_n) * p.K2 : 0;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int t) {
+    bf16_bits* sA = smem + ((t - t_begin) % STAGES) * STAGE_ELEMS;
+    bf16_bits* sB = sA + BM * PK;
+    if (t < T1) {
+      const int k0 = t * PK;
+      stage_tile32<BM, NW>(p.A, p.lda, m0, p.M - 1, k0, p.K, sA, wave, lane);
+      stage_tile32<BN, NW>(p.B, p.ldb, n0, p.N - 1, k0, p.K, sB, wave, lane);
+    } else {
+      const int k0 = (t - T1) * PK;
+      stage_tile32<BM, NW>(p.A2 + a2_col0, p.lda2, m0, p.M - 1, k0, p.K2, sA, wave, lane);
+      stage_tile32<BN, NW>(p.B2, p.ldb2, n0, p.N - 1, k0, p.K2, sB, wave, lane);
+    }
+  };
+
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (t_begin + s < t_end) stage(t_begin + s);
+
+  for (int t = t_begin; t < t_end; ++t) {
+    // stage t has landed once at most (stages issued after it) x G of this wave's DMAs are still outstanding
+    const int newer = (t_end - 1 - t) < (D - 1) ? (t_end - 1 - t) : (D - 1);
+    if (newer >= 3) wait_vmcnt<3 * G>();
+    else if (newer == 2) wait_vmcnt<2 * G>();
+    else if (newer == 1) wait_vmcnt<G>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // everyone's DMAs for stage t landed; everyone finished reading stage t-1
+    if (t + D < t_end) stage(t + D);  // refills the buffer stage t-1 used
+    const bf16_bits* sA = smem + ((t - t_begin) % STAGES) * STAGE_ELEMS;
+    const bf16_bits* sB = sA + BM * PK;
+    // fragment reads are software-pipelined against the MFMAs inside the stage: row i+1's A fragment is in flight
+    // while row i's NT MFMAs issue (sched_group_barrier pins the 1 ds_read : NT mfma interleave)
+    bf16x8_bits b[NT];
+    const int chunk = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b[j] = lds_frag32(sB, wn * WTN + j * 16 + (lane & 15), chunk);
+    bf16x8_bits a_cur = lds_frag32(sA, wm * WTM + (lane & 15), chunk);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      bf16x8_bits a_nxt = a_cur;
+      if (i + 1 < MT) a_nxt = lds_frag32(sA, wm * WTM + (i + 1) * 16 + (lane & 15), chunk);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a_cur, acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);  // NT MFMA
+      a_cur = a_nxt;
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  if (p.split_k > 1) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + 4 * (lane >> 4);
+        if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(p.ws + ((int64_t)split * p.M + m) * p.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
+  constexpr int LDSW = WTN + 4;
+  constexpr int RM = MT < 2 ? MT : 2;
+  constexpr int QUADS = WTN / 4;
+  float* wstage = reinterpret_cast<float*>(smem_raw) + wave * (RM * 16 * LDSW);
+#pragma unroll
+  for (int round = 0; round < MT / RM; ++round) {
+    __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii < RM; ++ii)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        *reinterpret_cast<f32x4*>(wstage + (ii * 16 + (lane & 15)) * LDSW + j * 16 + 4 * (lane >> 4)) = acc[round * RM + ii][j];
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < RM * 16 * QUADS / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int row = idx / QUADS, c4 = idx % QUADS;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wstage + row * LDSW + c4 * 4);
+      const int m = m0 + wm * WTM + round * RM * 16 + row;
+      const int n = n0 + wn * WTN + c4 * 4;
+      if (m < p.M && n < p.N) epilogue_store(p, m, n, v);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParams p) {
   const int64_t quads = (int64_t)p.M * (p.N / 4);
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
@@ -246,8 +452,55 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParam
   }
 }
 
+// sums the rem_splits partial slabs of every remainder tile and applies the epilogue
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_hybrid_reduce_kernel(const GemmParams p) {
+  const int rt = blockIdx.y;
+  const int t_mn = p.full_tiles + rt;
+  constexpr int GROUP = 8;
+  const int group_sz = GROUP * p.tiles_n;
+  const int gid = t_mn / group_sz;
+  const int first_m = gid * GROUP;
+  const int gm = (p.tiles_m - first_m) < GROUP ? (p.tiles_m - first_m) : GROUP;
+  const int in_group = t_mn - gid * group_sz;
+  const int m0 = (first_m + in_group % gm) * BM, n0 = (in_group / gm) * BN;
+  const float* slab0 = p.ws + (int64_t)rt * p.rem_splits * (BM * BN);
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < BM * BN / 4; q += gridDim.x * 256) {
+    const int lm = q / (BN / 4), ln = (q % (BN / 4)) * 4;
+    const int m = m0 + lm, n = n0 + ln;
+    if (m >= p.M || n >= p.N) continue;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int sidx = 0; sidx < p.rem_splits; ++sidx) v += *reinterpret_cast<const f32x4*>(slab0 + (int64_t)sidx * (BM * BN) + lm * BN + ln);
+    epilogue_store(p, m, n, v);
+  }
+}
+
+static int g_num_cus = 0;
+static int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    g_num_cus = n;
+  }
+  return g_num_cus;
+}
+
+// Picks the K split of the remainder tiles: minimises (last-round time) + (reduce traffic), both in units of seconds.
+static int pick_rem_splits(int rem_tiles, int slots, int T, double tile_flops, double per_slot_rate, double tile_bytes_f32, int64_t ws_floats,
+                           int bm_bn) {
+  int best = 1;
+  double best_t = tile_flops / per_slot_rate;   // unsplit: one more full tile time
+  for (int sp = 2; sp <= 8 && sp * 4 <= T; ++sp) {
+    if ((int64_t)rem_tiles * sp * bm_bn > ws_floats) break;
+    const int rounds = (rem_tiles * sp + slots - 1) / slots;
+    const double t = rounds * (tile_flops / sp) / per_slot_rate + 2.0 * rem_tiles * sp * tile_bytes_f32 / 2.5e12 + 4e-6;
+    if (t < best_t) { best_t = t; best = sp; }
+  }
+  return best;
+}
+
 template <int BM, int BN, int WM, int WN>
-int launch_cfg(GemmParams& p, hipStream_t stream) {
+int launch_cfg(GemmParams& p, hipStream_t stream, int64_t ws_bytes = 0, bool hybrid = false) {
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.N, BN);
   if (p.k2_group_n > 0 && (p.k2_group_n % BN) != 0) {
@@ -255,16 +508,73 @@ int launch_cfg(GemmParams& p, hipStream_t stream) {
     return OVLA_EINVAL;
   }
   const int splits = p.split_k > 1 ? p.split_k : 1;
-  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16_bits);
+  size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16_bits);
+  const size_t epi = (size_t)WM * WN * 32 * (BN / WN + 4) * sizeof(float);   // epilogue staging slabs reuse the same LDS
+  if (epi > lds) lds = epi;
   auto kern = gemm_nt_kernel<BM, BN, WM, WN>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * splits));
-  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, stream, p);
+  const int tiles = p.tiles_m * p.tiles_n;
+  p.full_tiles = tiles;
+  p.rem_tiles = 0;
+  p.rem_splits = 1;
+  if (hybrid && splits == 1 && p.ws != nullptr) {
+    const int bpc = lds <= 80 * 1024 ? 2 : 1;          // workgroups per CU (160 KiB LDS)
+    static_assert((size_t)WM * WN * 32 * (BN / WN + 4) * sizeof(float) <= 160 * 1024, "epilogue slabs exceed LDS");
+    const int slots = num_cus() * bpc;
+    const int rem = tiles % slots;
+    if (rem > 0 && rem * 2 <= slots) {
+      const double tile_flops = 2.0 * BM * BN * ((double)p.K + p.K2);
+      const double per_slot = (BM >= 256 && BN >= 256 ? 1.3e15 : 0.95e15) / slots;
+      const int sp = pick_rem_splits(rem, slots, p.T1 + p.T2, tile_flops, per_slot, 4.0 * BM * BN, ws_bytes / 4, BM * BN);
+      if (sp > 1) {
+        p.full_tiles = tiles - rem;
+        p.rem_tiles = rem;
+        p.rem_splits = sp;
+      }
+    }
+  }
+  const unsigned nblk = p.rem_tiles > 0 ? (unsigned)(p.full_tiles + p.rem_tiles * p.rem_splits) : (unsigned)(tiles * splits);
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * WM * WN), lds, stream, p);
   OVLA_CHECK_LAUNCH("ovla_gemm_bf16");
+  if (p.rem_tiles > 0) {
+    hipLaunchKernelGGL((gemm_hybrid_reduce_kernel<BM, BN>), dim3(BM * BN / 4 / 256 / 4, p.rem_tiles), dim3(256), 0, stream, p);
+    OVLA_CHECK_LAUNCH("ovla_gemm_bf16(hybrid reduce)");
+  } else if (splits > 1) {
+    const int64_t quads = (int64_t)p.M * (p.N / 4);
+    int blocks = cdiv(quads, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    OVLA_CHECK_LAUNCH("ovla_gemm_bf16(split-k reduce)");
+  }
+  return OVLA_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+int launch_pipe(GemmParams& p, hipStream_t stream) {
+  p.tiles_m = cdiv(p.M, BM);
+  p.tiles_n = cdiv(p.N, BN);
+  if (p.k2_group_n > 0 && (p.k2_group_n % BN) != 0) {
+    ovla_set_error("ovla_gemm_bf16: k2_group_n=%d is not a multiple of the N tile %d", p.k2_group_n, BN);
+    return OVLA_EINVAL;
+  }
+  const int T = cdiv(p.K, PK) + (p.K2 > 0 ? cdiv(p.K2, PK) : 0);
+  if (p.split_k > T) p.split_k = T;
+  const int splits = p.split_k > 1 ? p.split_k : 1;
+  size_t lds = (size_t)STAGES * (BM + BN) * PK * sizeof(bf16_bits);
+  const size_t epi = (size_t)WM * WN * 32 * (BN / WN + 4) * sizeof(float);
+  if (epi > lds) lds = epi;
+  auto kern = gemm_nt_pipe_kernel<BM, BN, WM, WN, STAGES>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_m * p.tiles_n * splits)), dim3(64 * WM * WN), lds, stream, p);
+  OVLA_CHECK_LAUNCH("ovla_gemm_bf16(pipe)");
   if (splits > 1) {
     const int64_t quads = (int64_t)p.M * (p.N / 4);
     int blocks = cdiv(quads, 256);
@@ -300,7 +610,9 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   if (a->bias) OVLA_REQUIRE((((uintptr_t)a->bias) & 7) == 0, "ovla_gemm_bf16: bias alignment");
   if (a->colscale) OVLA_REQUIRE((((uintptr_t)a->colscale) & 7) == 0, "ovla_gemm_bf16: colscale alignment");
   if (a->film_gamma) OVLA_REQUIRE(a->film_beta && a->film_rows > 0, "ovla_gemm_bf16: FiLM needs beta and film_rows");
-  if (a->split_k > 1) OVLA_REQUIRE(a->workspace != nullptr && aligned16(a->workspace), "ovla_gemm_bf16: split_k needs a 16-byte aligned workspace");
+  if (a->split_k > 1)
+    OVLA_REQUIRE(a->workspace != nullptr && aligned16(a->workspace) && a->workspace_bytes >= ovla_gemm_workspace_bytes(a->M, a->N, a->split_k),
+                 "ovla_gemm_bf16: split_k=%d needs a 16-byte aligned workspace of %lld bytes", a->split_k, (long long)ovla_gemm_workspace_bytes(a->M, a->N, a->split_k));
 
   GemmParams p;
   p.A = (const bf16_bits*)a->A; p.B = (const bf16_bits*)a->B;
@@ -316,13 +628,41 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
   p.T1 = cdiv(p.K, BK); p.T2 = p.K2 > 0 ? cdiv(p.K2, BK) : 0;
   if (p.split_k > p.T1 + p.T2) p.split_k = p.T1 + p.T2;
+  p.full_tiles = 0; p.rem_tiles = 0; p.rem_splits = 1;
 
   int tile = a->tile;
-  if (tile == 0) tile = (a->M <= 64) ? 2 : 1;
+  const int64_t wsb = a->workspace ? a->workspace_bytes : 0;
+  bool hybrid = false;
+  if (tile == 0) {
+    // auto schedule.  Skinny outputs (LoRA t / dt, N <= 128) and small M (action head) are HBM-bound weight/activation
+    // streams: split K so that >= ~256 workgroups stream concurrently.  Large problems take the 256x256 tile (in-kernel
+    // ~1.3 PFLOP/s) with the hybrid remainder schedule; mid-size ones the 128x128 tile (2 workgroups per CU).
+    const int T = p.T1 + p.T2;
+    auto want_split = [&](int tiles) {
+      int sp = 1;
+      while (sp < 8 && tiles * sp < 256 && (sp * 2) * 8 <= T && ovla_gemm_workspace_bytes(p.M, p.N, sp * 2) <= wsb) sp *= 2;
+      return sp;
+    };
+    if (p.N <= 32) { tile = 5; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 128)); }
+    else if (p.M <= 64 || p.N <= 128) { tile = 2; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 64) * cdiv(p.N, 128)); }
+    else if ((int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 200 && p.K >= 2048 && (p.k2_group_n == 0 || p.k2_group_n % 256 == 0)) { tile = 17; hybrid = true; }
+    else { tile = 1; hybrid = true; }
+  }
   switch (tile) {
-    case 1: return launch_cfg<128, 128, 2, 2>(p, stream);
+    case 1: return launch_cfg<128, 128, 2, 2>(p, stream, wsb, hybrid);
     case 2: return launch_cfg<64, 128, 1, 4>(p, stream);
     case 3: return launch_cfg<256, 128, 4, 2>(p, stream);
+    case 5: return launch_cfg<128, 32, 4, 1>(p, stream);
+    case 10: return launch_pipe<256, 256, 2, 4, 4>(p, stream);
+    case 11: return launch_pipe<256, 128, 2, 4, 5>(p, stream);
+    case 12: return launch_pipe<256, 128, 4, 2, 5>(p, stream);
+    case 13: return launch_pipe<128, 256, 2, 4, 5>(p, stream);
+    case 14: return launch_pipe<128, 128, 2, 2, 4>(p, stream);
+    case 15: return launch_pipe<256, 256, 2, 4, 3>(p, stream);
+    case 16: return launch_cfg<256, 256, 2, 4>(p, stream);
+    case 17: return launch_cfg<256, 256, 4, 2>(p, stream, wsb, hybrid);
+    case 117: return launch_cfg<256, 256, 4, 2>(p, stream, wsb, true);
+    case 101: return launch_cfg<128, 128, 2, 2>(p, stream, wsb, true);
     default: ovla_set_error("ovla_gemm_bf16: unknown tile id %d", tile); return OVLA_EINVAL;
   }
 }

@@ -17,6 +17,18 @@ BF16 = torch.bfloat16
 PROFILE = None
 
 
+_WS_BYTES = 96 << 20   # persistent fp32 scratch per device for split-K / hybrid-schedule partial sums (stream-ordered reuse)
+_ws_cache = {}
+
+
+def _workspace(device, nbytes):
+    ws = _ws_cache.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes, _WS_BYTES) // 4, dtype=torch.float32, device=device)
+        _ws_cache[device] = ws
+    return ws
+
+
 def _prof_begin():
     if PROFILE is None:
         return None
@@ -87,10 +99,8 @@ def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=Non
         assert gamma.shape[-1] == N and gamma.is_contiguous() and beta.is_contiguous()
         g.film_gamma, g.film_beta, g.film_rows = gamma.data_ptr(), beta.data_ptr(), rows
     g.M, g.N, g.K, g.act, g.split_k, g.tile, g.alpha = M, N, K, act, split_k, tile, alpha
-    ws = None
-    if split_k > 1:
-        ws = torch.empty((split_k, M, N), dtype=torch.float32, device=a.device)
-        g.workspace = ws.data_ptr()
+    ws = _workspace(a.device, max(4 * split_k * M * N if split_k > 1 else 0, _WS_BYTES))
+    g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     e0 = _prof_begin()
     _lib.call("ovla_gemm_bf16", g, _stream())
     _prof_end(e0, "gemm_nt", 2.0 * M * N * (K + (b2.shape[1] if b2 is not None else 0)))

@@ -58,7 +58,7 @@ GEMM_SHAPES = [(128, 128, 64), (200, 136, 72), (1000, 512, 1024), (64, 256, 2048
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 10, 11, 12, 13, 14, 15, 16, 17])
 def test_gemm_plain(ops, dev, M, N, K, tile):
     torch.manual_seed(M * 7 + N * 3 + K + tile)
     a, b = rnd(M, K, dev=dev), rnd(N, K, dev=dev)
@@ -67,14 +67,15 @@ def test_gemm_plain(ops, dev, M, N, K, tile):
     close(out, ref, what=f"gemm {M}x{N}x{K} tile {tile}")
 
 
+@pytest.mark.parametrize("tile", [0, 10])
 @pytest.mark.parametrize("act", [0, 1, 2, 3, 4])
-def test_gemm_epilogue(ops, dev, act):
+def test_gemm_epilogue(ops, dev, act, tile):
     torch.manual_seed(act)
     M, N, K = 333, 264, 520
     a, b = rnd(M, K, dev=dev, scale=0.5), rnd(N, K, dev=dev, scale=0.1)
     bias, cs, res = rnd(N, dev=dev), rnd(N, dev=dev), rnd(M, N, dev=dev)
     pre = torch.empty((M, N), dtype=BF, device=dev)
-    out = ops.gemm(a, b, bias=bias, act=act, colscale=cs, residual=res, c_pre=pre)
+    out = ops.gemm(a, b, bias=bias, act=act, colscale=cs, residual=res, c_pre=pre, tile=tile)
     z = (a.float() @ b.float().T + bias.float()).to(BF)
     close(pre, z, what="c_pre")
     zf = z.float()
@@ -94,28 +95,51 @@ def test_gemm_film_epilogue(ops, dev):
     close(out, ref, what="film epilogue")
 
 
+@pytest.mark.parametrize("tile", [0, 10, 11, 14])
 @pytest.mark.parametrize("groups,K2", [(1, 32), (3, 32), (2, 64), (1, 16)])
-def test_gemm_lora_extension(ops, dev, groups, K2):
+def test_gemm_lora_extension(ops, dev, groups, K2, tile):
     torch.manual_seed(groups * 10 + K2)
     M, Ng, K = 300, 256, 192
     N = Ng * groups
     a, b = rnd(M, K, dev=dev), rnd(N, K, dev=dev, scale=0.1)
     t, lb = rnd(M, groups * K2, dev=dev), rnd(N, K2, dev=dev, scale=0.2)
-    out = ops.gemm(a, b, a2=t, b2=lb, k2_group_n=Ng if groups > 1 else 0)
+    out = ops.gemm(a, b, a2=t, b2=lb, k2_group_n=Ng if groups > 1 else 0, tile=tile)
     ref = a.float() @ b.float().T
     for g in range(groups):
         ref[:, g * Ng:(g + 1) * Ng] += t[:, g * K2:(g + 1) * K2].float() @ lb[g * Ng:(g + 1) * Ng].float().T
     close(out, ref.to(BF), what=f"lora k-extension groups={groups} K2={K2}")
 
 
+@pytest.mark.parametrize("tile", [0, 10, 5])
 @pytest.mark.parametrize("split_k", [2, 8])
-def test_gemm_split_k(ops, dev, split_k):
+def test_gemm_split_k(ops, dev, split_k, tile):
     torch.manual_seed(split_k)
     M, N, K = 64, 384, 4096
     a, b, bias = rnd(M, K, dev=dev, scale=0.3), rnd(N, K, dev=dev, scale=0.1), rnd(N, dev=dev)
-    out = ops.gemm(a, b, bias=bias, act=2, split_k=split_k)
+    out = ops.gemm(a, b, bias=bias, act=2, split_k=split_k, tile=tile)
     ref = torch.relu((a.float() @ b.float().T + bias.float()).to(BF).float()).to(BF)
     close(out, ref, what=f"split_k {split_k}")
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(4864, 4096, 1024, 117), (4864, 4096, 1024, 0), (1300, 1152, 512, 101), (2500, 2304, 2048, 117), (300, 520, 256, 101)])
+def test_gemm_hybrid_schedule(ops, dev, M, N, K, tile):
+    """Full rounds data-parallel + remainder tiles split along K (partial slabs + reduce kernel with the epilogue)."""
+    torch.manual_seed(M + N + K)
+    a, b = rnd(M, K, dev=dev, scale=0.5), rnd(N, K, dev=dev, scale=0.1)
+    bias, res = rnd(N, dev=dev), rnd(M, N, dev=dev)
+    t, lb = rnd(M, 32, dev=dev), rnd(N, 32, dev=dev, scale=0.2)
+    out = ops.gemm(a, b, bias=bias, act=1, residual=res, a2=t, b2=lb, tile=tile)
+    z = (a.float() @ b.float().T + t.float() @ lb.float().T + bias.float()).to(BF).float()
+    ref = (torch.nn.functional.gelu(z).to(BF).float() + res.float()).to(BF)
+    close(out, ref, what=f"hybrid {M}x{N}x{K} tile {tile}")
+
+
+def test_gemm_auto_skinny(ops, dev):
+    """tile=0 picks split-K for skinny outputs (LoRA t / dt) and small M (action head)."""
+    torch.manual_seed(12)
+    for M, N, K in [(4864, 96, 4096), (4864, 32, 11008), (64, 4096, 28672), (1000, 64, 1152)]:
+        a, b = rnd(M, K, dev=dev, scale=0.3), rnd(N, K, dev=dev, scale=0.1)
+        close(ops.gemm(a, b, alpha=0.5), (0.5 * (a.float() @ b.float().T)).to(BF), what=f"auto skinny {M}x{N}x{K}")
 
 
 def test_gemm_strided_views(ops, dev):

@@ -38,8 +38,13 @@ for name, m, n, k, k2 in SHAPES:
     fl = 2.0 * m * n * k
     res = []
     for t in tiles:
-        if m <= 64:
+        if t == 0:
+            ms = bench(lambda: ops.gemm(a, b, out=out))
+        elif m <= 64:
             ms = bench(lambda: ops.gemm(a, b, out=out, tile=2, split_k=8))
+        elif n <= 128:
+            sk = {1: 1, 3: 1}.get(t, 4)
+            ms = bench(lambda: ops.gemm(a, b, out=out, tile=(5 if n <= 32 else 2) if t >= 10 else t, split_k=sk))
         else:
             ms = bench(lambda: ops.gemm(a, b, out=out, tile=t))
         res.append(fl / ms / 1e9)
