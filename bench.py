@@ -157,17 +157,17 @@ def main():
     batch["actions"] = batch["actions"].to(dev, torch.bfloat16)
     batch["proprio"] = batch["proprio"].to(dev, torch.bfloat16)
     S = 1 + cfg.num_images * cfg.dino.n_patches + 1 + (batch["input_ids"].shape[1] - 1)
-    reducer = dp_mod.GradReducer(eng.store, world) if world > 1 else None
+    reducer = dp_mod.GradReducer(eng.stores, world) if world > 1 else None
     if rank == 0:
-        print(f"[bench] init {time.time() - t_init:.1f}s, trainable params {eng.store.num_trainable() / 1e6:.1f} M, S={S}, "
+        print(f"[bench] init {time.time() - t_init:.1f}s, trainable params {eng.num_trainable() / 1e6:.1f} M, S={S}, "
               f"HBM allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB", file=sys.stderr)
 
     def step():
-        eng.store.zero_grad()
+        eng.zero_grad()
         loss_sum, count, _ = eng.train_step_fwd_bwd(batch)
         if reducer is not None:
             reducer.all_reduce()
-        eng.store.adamw_step(lr=5e-4, grad_scale=1.0 / world)
+        eng.adamw_step(lr=5e-4, grad_scale=1.0 / world)
         eng.refresh_derived()
         return loss_sum
 

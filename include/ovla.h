@@ -258,6 +258,7 @@ typedef struct {
 int ovla_head_out_fwd(const ovla_head_out_fwd_args* a, void* stream);
 typedef struct {
   const void* x; const void* W; const void* pred; const void* target;
+  const void* dpred;            /* optional bf16 [rows, adim]: explicit upstream gradient (pred/target/mse then ignored) */
   float dloss_scale;            /* dloss / (rows*adim) */
   int32_t mse;                  /* 0: L1 (sign), 1: MSE (2*(pred-target)) */
   void* dx; float* dW; float* db;

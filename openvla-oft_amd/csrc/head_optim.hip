@@ -51,10 +51,14 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const bf16_bits* __re
 // bf16(2 (pred-target) * scale) (MSE);  dx[m,c] = sum_a dpred[m,a] W[a,c];  dW[a,c] += sum_m dpred[m,a] x[m,c]
 __global__ __launch_bounds__(256) void head_out_bwd_kernel(const bf16_bits* __restrict__ x, const bf16_bits* __restrict__ W,
                                                            const bf16_bits* __restrict__ pred, const bf16_bits* __restrict__ target,
-                                                           float scale, int mse, bf16_bits* __restrict__ dx, float* __restrict__ dW,
+                                                           const bf16_bits* __restrict__ dpred, float scale, int mse, bf16_bits* __restrict__ dx, float* __restrict__ dW,
                                                            float* __restrict__ db, int rows, int dim, int adim) {
   extern __shared__ float dp[];  // [rows][adim]
   for (int i = threadIdx.x; i < rows * adim; i += 256) {
+    if (dpred) {
+      dp[i] = bf2f(dpred[i]);
+      continue;
+    }
     const float d = bfround(bf2f(pred[i]) - bf2f(target[i]));
     float g;
     if (mse) g = bfround(2.f * d * scale);
@@ -156,12 +160,12 @@ extern "C" int ovla_head_out_fwd(const ovla_head_out_fwd_args* a, void* stream_)
 
 extern "C" int ovla_head_out_bwd(const ovla_head_out_bwd_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  OVLA_REQUIRE(a && a->x && a->W && a->pred && a->target && a->dx, "ovla_head_out_bwd: null pointer");
+  OVLA_REQUIRE(a && a->x && a->W && a->dx && (a->dpred || (a->pred && a->target)), "ovla_head_out_bwd: null pointer");
   OVLA_REQUIRE(a->rows > 0 && a->dim > 0 && a->adim > 0 && a->adim <= MAX_ADIM, "ovla_head_out_bwd: rows=%d dim=%d adim=%d", a->rows, a->dim, a->adim);
   const size_t lds = (size_t)a->rows * a->adim * sizeof(float);
   OVLA_REQUIRE(lds <= 48 * 1024, "ovla_head_out_bwd: rows*adim too large for the LDS slab");
   hipLaunchKernelGGL(head_out_bwd_kernel, dim3(cdiv(a->dim, 256)), dim3(256), lds, stream, (const bf16_bits*)a->x, (const bf16_bits*)a->W,
-                     (const bf16_bits*)a->pred, (const bf16_bits*)a->target, a->dloss_scale, a->mse, (bf16_bits*)a->dx, a->dW, a->db, a->rows,
+                     (const bf16_bits*)a->pred, (const bf16_bits*)a->target, (const bf16_bits*)a->dpred, a->dloss_scale, a->mse, (bf16_bits*)a->dx, a->dW, a->db, a->rows,
                      a->dim, a->adim);
   OVLA_CHECK_LAUNCH("ovla_head_out_bwd");
   return OVLA_OK;

@@ -13,16 +13,17 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, store, world: int, bucket_bytes: int = 256 << 20):
-        self.store, self.world = store, world
+    def __init__(self, stores, world: int, bucket_bytes: int = 256 << 20):
+        self.stores, self.world = list(stores), world
         self.bucket_elems = bucket_bytes // 4
         self.comm_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
 
     def buckets(self):
-        for g in self.store.flat_grad.values():
-            n = g.numel()
-            for off in range(0, n, self.bucket_elems):
-                yield g[off: min(n, off + self.bucket_elems)]
+        for store in self.stores:
+            for g in store.flat_grad.values():
+                n = g.numel()
+                for off in range(0, n, self.bucket_elems):
+                    yield g[off: min(n, off + self.bucket_elems)]
 
     def all_reduce(self):
         """Sum-reduces every gradient bucket across ranks on the communication stream and makes the compute stream wait

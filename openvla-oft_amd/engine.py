@@ -414,7 +414,7 @@ class LlamaStack:
 # MLPResNet action head (prismatic/models/action_heads.py:38-107; L1 loss finetune.py:400, MSE :407)
 # ======================================================================================================================
 class ActionHead:
-    def __init__(self, store, cfg: VLAConfig, get, prefix: str):
+    def __init__(self, store, get, prefix: str, cfg: VLAConfig):
         D, A = cfg.llm_dim, cfg.action_dim
         self.cfg, self.prefix = cfg, prefix
         self.ln1_w = store.add(prefix + "layer_norm1.weight", get(prefix + "layer_norm1.weight"))
@@ -464,12 +464,15 @@ class ActionHead:
         saved = (x0, m0, r0, z1, s1, blocks_saved, x, m2, r2, h2, pred, target, mse) if train else None
         return pred, loss_sum, saved
 
-    def bwd(self, saved, dloss: float = 1.0):
-        """Returns d(actions_hidden) [B*A_tokens, D]; accumulates the head's gradients."""
+    def bwd(self, saved, dloss: float = 1.0, dpred=None):
+        """Returns d(actions_hidden) [B*A_tokens, D]; accumulates the head's gradients.  With `dpred` (bf16
+        [rows, action_dim]) the upstream gradient is taken as given (loss computed by the caller); otherwise the fused
+        L1 / MSE gradient of mean-reduced loss * dloss is used."""
         cfg = self.cfg
         x0, m0, r0, z1, s1, blocks_saved, xl, m2, r2, h2, pred, target, mse = saved
         rows = x0.shape[0]
-        dh2 = ops.head_out_bwd(h2, self.out_w.data, pred, target, dloss / (rows * cfg.action_dim), self.out_w.grad, self.out_b.grad, mse=mse)
+        dh2 = ops.head_out_bwd(h2, self.out_w.data, pred, target, dloss / (rows * cfg.action_dim), self.out_w.grad, self.out_b.grad, mse=mse,
+                               dpred=dpred)
         dx = ops.norm_bwd(xl, dh2, self.ln2_w.data, m2, r2, rms=False, dweight=self.ln2_w.grad, dbias=self.ln2_b.grad)
         for b, (xin, mb, rb, zb, sb) in zip(reversed(self.blocks), reversed(blocks_saved)):
             dz = ops.act_bwd(zb, dx, ops.ACT_RELU)
@@ -486,6 +489,7 @@ class MlpProjector:
     prismatic/models/projectors.py:6-49)."""
 
     def __init__(self, store, get, prefix: str):
+        self.prefix = prefix
         self.fc1 = FullLinear(store, prefix + "fc1", get(prefix + "fc1.weight").float(), get(prefix + "fc1.bias").float(), master_fp32=True)
         self.fc2 = FullLinear(store, prefix + "fc2", get(prefix + "fc2.weight").float(), get(prefix + "fc2.bias").float(), master_fp32=True)
 
@@ -508,6 +512,17 @@ class MlpProjector:
         dh = self.fc2.bwd(dy, s2)
         dz = ops.act_bwd(z, dh, ops.ACT_GELU)
         self.fc1.bwd(dz, s1, need_dx=False)
+
+
+def build_component(cls, device, get, prefix, **kw):
+    """Builds a stand-alone component (its own ParamStore) from reference-named tensors."""
+    st = ParamStore(device)
+    comp = cls(st, get=get, prefix=prefix, **kw)
+    st.finalize()
+    comp.store = st
+    for lin in comp.linears():
+        lin.refresh_derived()
+    return comp
 
 
 # ======================================================================================================================
@@ -536,17 +551,38 @@ class VLAEngine:
                               get(name + ".lora_B.weight") if lora else None, 1, s)
 
         self.proj = [L("projector.fc1"), L("projector.fc2"), L("projector.fc3")]
-        self.proprio = MlpProjector(st, get, "proprio_projector.") if use_proprio else None
-        self.noisy = MlpProjector(st, get, "noisy_action_projector.") if head == "diffusion" else None
         self.embed = get("language_model.model.embed_tokens.weight")
         self.llm = LlamaStack(st, cfg, get, lora)
         self.lm_head = get("language_model.lm_head.weight") if (has is None or has("language_model.lm_head.weight")) else None
-        self.head_kind = head
-        self.head = None
-        if head != "none":
-            self.head = ActionHead(st, cfg, get, "action_head.noise_predictor.mlp_resnet." if head == "diffusion" else "action_head.model.")
         st.finalize()
+        # components are separate modules with their own parameter stores, like the reference's DDP-wrapped
+        # ProprioProjector / action head / NoisyActionProjector (finetune.py:894-932); they can also be built standalone
+        # (modeling.py) and passed in per call.
+        self.proprio = self.noisy = self.head = None
+        self.head_kind = head
+        if use_proprio:
+            self.proprio = build_component(MlpProjector, device, get, "proprio_projector.")
+        if head == "diffusion":
+            self.noisy = build_component(MlpProjector, device, get, "noisy_action_projector.")
+        if head != "none":
+            self.head = build_component(ActionHead, device, get, "action_head.noise_predictor.mlp_resnet." if head == "diffusion" else "action_head.model.",
+                                        cfg=cfg)
         self.refresh_derived()
+
+    @property
+    def stores(self):
+        return [self.store] + [m.store for m in (self.proprio, self.noisy, self.head) if m is not None]
+
+    def zero_grad(self):
+        for st in self.stores:
+            st.zero_grad()
+
+    def adamw_step(self, lr: float, **kw):
+        for st in self.stores:
+            st.adamw_step(lr, **kw)
+
+    def num_trainable(self):
+        return sum(st.num_trainable() for st in self.stores)
 
     # -- bookkeeping -----------------------------------------------------------------------------------------------------
     def all_linears(self):
@@ -556,6 +592,12 @@ class VLAEngine:
         for m in (self.proprio, self.noisy, self.head):
             if m is not None:
                 yield from m.linears()
+        yield from self.llm.linears()
+
+    def vlm_linears(self):
+        yield from self.dino.linears()
+        yield from self.siglip.linears()
+        yield from self.proj
         yield from self.llm.linears()
 
     def refresh_derived(self):
@@ -574,6 +616,10 @@ class VLAEngine:
             for p in self.head.plain_params():
                 out[p.name] = getattr(p, kind)
         return out
+
+    def num_patches_total(self, num_images: int, use_proprio: bool, use_diffusion: bool = False) -> int:
+        """NUM_PATCHES of finetune.py:935-941."""
+        return self.cfg.dino.n_patches * num_images + int(use_proprio) + int(use_diffusion)
 
     # -- forward pieces ----------------------------------------------------------------------------------------------------
     def vision_fwd(self, pixel_values, train: bool):
@@ -619,7 +665,8 @@ class VLAEngine:
             tower.bwd(dtok, tower_saved[k])
 
     # -- the training step pieces -------------------------------------------------------------------------------------------
-    def forward(self, input_ids, attention_mask, pixel_values, labels, proprio=None, noisy_actions=None, timestep_emb=None, train=False):
+    def forward(self, input_ids, attention_mask, pixel_values, labels, proprio=None, noisy_actions=None, timestep_emb=None, train=False,
+                proprio_projector=None, noisy_action_projector=None):
         """Multimodal forward (modeling_prismatic.py:571-643 without the discarded lm_head/CE in L1/diffusion mode).
         Returns dict(hidden [B,S,D], P, action_rows [B,A], saved)."""
         cfg = self.cfg
@@ -632,11 +679,13 @@ class VLAEngine:
         if not bool((am == (torch.arange(L)[None, :] < lens[:, None])).all()):
             raise ValueError("attention_mask must be right padding (a prefix of ones per row), as produced by the reference collator")
         patches, vsaved = self.vision_fwd(pixel_values.to(dev, BF16).contiguous(), train)
+        proprio_projector = proprio_projector if proprio_projector is not None else self.proprio
+        noisy_action_projector = noisy_action_projector if noisy_action_projector is not None else self.noisy
         extra, psaved, nsaved = [], None, None
-        if proprio is not None and self.proprio is not None:
+        if proprio is not None and proprio_projector is not None:
             pr = torch.zeros(((B + 7) // 8 * 8, cfg.proprio_dim), dtype=BF16, device=dev)
             pr[:B] = proprio.reshape(B, -1).to(dev, BF16)
-            pf, psaved = self.proprio.fwd(pr, train)
+            pf, psaved = proprio_projector.fwd(pr, train)
             extra.append(pf[:B].reshape(B, 1, cfg.llm_dim))
         if timestep_emb is not None:
             extra.append(timestep_emb.to(dev, BF16).reshape(B, 1, cfg.llm_dim))
@@ -653,13 +702,13 @@ class VLAEngine:
         noisy_feats = None
         if noisy_actions is not None:
             na = noisy_actions.reshape(B * A, 1).to(dev, BF16)
-            nf, nsaved = self.noisy.fwd(na, train)
+            nf, nsaved = noisy_action_projector.fwd(na, train)
             noisy_feats = nf.view(B, A, cfg.llm_dim)
         mm, action_rows = ops.assemble_multimodal(ids, lab, self.embed, allp.contiguous(), A=A, noisy=noisy_feats, action_dim=cfg.action_dim)
         S = P + L
         kv_len = (lens + P).to(torch.int32).to(dev)
         hidden, lsaved = self.llm.fwd(mm.view(B * S, cfg.llm_dim), B, S, kv_len, train)
-        saved = (vsaved, psaved, nsaved, lsaved, B, S, P, patches.shape[1]) if train else None
+        saved = (vsaved, psaved, nsaved, lsaved, B, S, P, patches.shape[1], proprio_projector, noisy_action_projector) if train else None
         return dict(hidden=hidden.view(B, S, cfg.llm_dim), P=P, action_rows=action_rows, saved=saved)
 
     def gather_action_hidden(self, hidden, action_rows):
@@ -670,27 +719,33 @@ class VLAEngine:
         idx = action_rows.reshape(-1)
         return ops.gather_rows(hidden.view(B * S, D), idx, D), idx
 
-    def train_step_fwd_bwd(self, batch: dict, loss_scale: float = 1.0):
-        """One run_forward_pass (finetune.py:280-451, L1 branch) + backward.  Gradients accumulate in the flat buffers.
-        Returns (loss_sum fp32[1] device, count)."""
-        cfg = self.cfg
-        out = self.forward(batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["labels"], proprio=batch.get("proprio"),
-                           train=True)
-        hidden, P = out["hidden"], out["P"]
-        B, S, D = hidden.shape
-        ah, idx = self.gather_action_hidden(hidden, out["action_rows"])
-        target = batch["actions"].to(self.device, BF16).reshape(B * cfg.chunk, cfg.action_dim).contiguous()
-        pred, loss_sum, hsaved = self.head.fwd(ah, target=target, mse=False, train=True)
-        # ---- backward ----
-        dah = self.head.bwd(hsaved, dloss=loss_scale)
-        dhidden = torch.zeros((B * S, D), dtype=BF16, device=self.device)
-        ops.gather_rows(dah, idx, D, dst=dhidden, scatter_add=True)
-        vsaved, psaved, nsaved, lsaved, _, _, _, n_vis = out["saved"]
+    def backward_from_hidden(self, dhidden, saved):
+        """dhidden bf16 [B*S, D] (gradient of hidden_states[-1]) -> accumulates every VLM / projector gradient."""
+        vsaved, psaved, nsaved, lsaved, B, S, P, n_vis, proprio_projector, noisy_action_projector = saved
+        D = self.cfg.llm_dim
         dmm = self.llm.bwd(dhidden, lsaved).view(B, S, D)
         if psaved is not None:
             dpr = torch.zeros(((B + 7) // 8 * 8, D), dtype=BF16, device=self.device)
             dpr[:B] = dmm[:, 1 + n_vis]
-            self.proprio.bwd(dpr, psaved)
+            proprio_projector.bwd(dpr, psaved)
         dpatches = dmm[:, 1: 1 + n_vis].contiguous().view(B * n_vis, D)
         self.vision_bwd(dpatches, vsaved)
+
+    def train_step_fwd_bwd(self, batch: dict, loss_scale: float = 1.0, action_head=None, proprio_projector=None):
+        """One run_forward_pass (finetune.py:280-451, L1 branch) + backward.  Gradients accumulate in the flat buffers.
+        Returns (loss_sum fp32[1] device, element count, predictions)."""
+        cfg = self.cfg
+        head = action_head if action_head is not None else self.head
+        out = self.forward(batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["labels"], proprio=batch.get("proprio"),
+                           train=True, proprio_projector=proprio_projector)
+        hidden = out["hidden"]
+        B, S, D = hidden.shape
+        ah, idx = self.gather_action_hidden(hidden, out["action_rows"])
+        target = batch["actions"].to(self.device, BF16).reshape(B * cfg.chunk, cfg.action_dim).contiguous()
+        pred, loss_sum, hsaved = head.fwd(ah, target=target, mse=False, train=True)
+        # ---- backward ----
+        dah = head.bwd(hsaved, dloss=loss_scale)
+        dhidden = torch.zeros((B * S, D), dtype=BF16, device=self.device)
+        ops.gather_rows(dah, idx, D, dst=dhidden, scatter_add=True)
+        self.backward_from_hidden(dhidden, out["saved"])
         return loss_sum, pred.numel(), pred

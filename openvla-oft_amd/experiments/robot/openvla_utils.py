@@ -1,0 +1,151 @@
+"""Inference glue (mirror of experiments/robot/openvla_utils.py: get_vla :253, get_processor :380, get_proprio_projector
+:393, get_action_head :463, normalize_proprio :645, prepare_images_for_vla :678, get_vla_action :711).
+
+Differences forced by the offline MI355X environment, all explicit:
+  * checkpoints are local directories of safetensors / .pt files in the reference layout (no HF-hub fetch);
+  * the processor wraps a caller-supplied tokenizer (no tokenizer files exist offline) -- anything with
+    `__call__(text) -> list[int]` works, e.g. transformers.LlamaTokenizerFast when its files are present.
+"""
+from __future__ import annotations
+
+import json
+import os
+from pathlib import Path
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from ... import image_prep
+from ...config import OPENVLA_7B, VLAConfig
+from ...modeling import L1RegressionActionHead, NoisyActionProjector, OpenVLAForActionPrediction, ProprioProjector
+from ...prismatic.vla import constants as C
+
+DEVICE = torch.device("cuda:0") if torch.cuda.is_available() else torch.device("cpu")
+OPENVLA_IMAGE_SIZE = 224
+
+
+def _load_tensors(path: Path) -> Dict[str, torch.Tensor]:
+    if path.suffix == ".safetensors":
+        from safetensors.torch import load_file
+
+        return load_file(str(path))
+    return torch.load(str(path), weights_only=True, map_location="cpu")
+
+
+def load_component_state_dict(checkpoint_path) -> Dict[str, torch.Tensor]:
+    """openvla_utils.py:230-250 (strips DDP's `module.` prefix)."""
+    sd = _load_tensors(Path(checkpoint_path))
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+
+
+def find_checkpoint_file(pretrained_checkpoint: str, file_pattern: str) -> str:
+    """openvla_utils.py:201-227"""
+    files = [os.path.join(pretrained_checkpoint, f) for f in os.listdir(pretrained_checkpoint) if file_pattern in f and "checkpoint" in f]
+    assert len(files) == 1, f"Expected exactly 1 {file_pattern} checkpoint but found {len(files)} in directory: {pretrained_checkpoint}"
+    return files[0]
+
+
+def get_vla(cfg: Any, model_config: VLAConfig = OPENVLA_7B) -> OpenVLAForActionPrediction:
+    """Loads the HF-layout checkpoint shards of `cfg.pretrained_checkpoint` (safetensors) into the HIP engine."""
+    ckpt = Path(cfg.pretrained_checkpoint)
+    if not ckpt.is_dir():
+        raise ValueError(f"`{ckpt}` is not a local checkpoint directory (HF-hub checkpoints cannot be fetched offline)")
+    if getattr(cfg, "load_in_8bit", False) or getattr(cfg, "load_in_4bit", False):
+        raise NotImplementedError("bitsandbytes quantised loading is not part of the MI355X path")
+    sd: Dict[str, torch.Tensor] = {}
+    for shard in sorted(ckpt.glob("*.safetensors")):
+        sd.update(_load_tensors(shard))
+    if not sd:
+        raise ValueError(f"no *.safetensors shards in {ckpt}")
+    vla = OpenVLAForActionPrediction(model_config, sd, device=DEVICE)
+    vla.vision_backbone.set_num_images_in_input(cfg.num_images_in_input)
+    stats = ckpt / "dataset_statistics.json"
+    if stats.is_file():                                                     # openvla_utils.py:352-377
+        vla.norm_stats = json.loads(stats.read_text())
+    vla.eval()
+    return vla
+
+
+def get_proprio_projector(cfg: Any, llm_dim: int, proprio_dim: int) -> ProprioProjector:
+    sd = load_component_state_dict(find_checkpoint_file(cfg.pretrained_checkpoint, "proprio_projector"))
+    return ProprioProjector(llm_dim, proprio_dim, device=DEVICE, state_dict=sd).eval()
+
+
+def get_noisy_action_projector(cfg: Any, llm_dim: int) -> NoisyActionProjector:
+    sd = load_component_state_dict(find_checkpoint_file(cfg.pretrained_checkpoint, "noisy_action_projector"))
+    return NoisyActionProjector(llm_dim, device=DEVICE, state_dict=sd).eval()
+
+
+def get_action_head(cfg: Any, llm_dim: int):
+    assert not (cfg.use_l1_regression and cfg.use_diffusion), "Cannot use both L1 regression and diffusion action head!"
+    if cfg.use_diffusion:
+        raise NotImplementedError("DiffusionActionHead is not built yet in this port (SURVEY.md section 8, row a11)")
+    if not cfg.use_l1_regression:
+        raise ValueError("Either use_l1_regression or use_diffusion must be True")
+    sd = load_component_state_dict(find_checkpoint_file(cfg.pretrained_checkpoint, "action_head"))
+    return L1RegressionActionHead(llm_dim, llm_dim, C.ACTION_DIM, num_actions_chunk=C.NUM_ACTIONS_CHUNK, device=DEVICE, state_dict=sd).eval()
+
+
+class PrismaticProcessor:
+    """processor(prompt, image) -> {"input_ids", "attention_mask", "pixel_values"} (processing_prismatic.py:175-252)."""
+
+    def __init__(self, tokenizer):
+        self.tokenizer = tokenizer
+
+    def __call__(self, text: str, image: np.ndarray):
+        ids = list(self.tokenizer(text))
+        return {"input_ids": torch.tensor([ids], dtype=torch.int64), "attention_mask": torch.ones((1, len(ids)), dtype=torch.bool),
+                "pixel_values": image_prep.apply_transform(np.asarray(image))[None]}
+
+
+def get_processor(cfg: Any, tokenizer=None) -> PrismaticProcessor:
+    if tokenizer is None:
+        from transformers import AutoTokenizer  # needs tokenizer files inside the checkpoint directory
+
+        tok = AutoTokenizer.from_pretrained(cfg.pretrained_checkpoint)
+        tokenizer = lambda text: tok(text, add_special_tokens=True).input_ids  # noqa: E731
+    return PrismaticProcessor(tokenizer)
+
+
+def normalize_proprio(proprio: np.ndarray, norm_stats: Dict[str, Any]) -> np.ndarray:
+    """openvla_utils.py:645-675"""
+    if C.ACTION_PROPRIO_NORMALIZATION_TYPE == C.NormalizationType.BOUNDS:
+        mask = norm_stats.get("mask", np.ones_like(norm_stats["min"], dtype=bool))
+        high, low = np.array(norm_stats["max"]), np.array(norm_stats["min"])
+    elif C.ACTION_PROPRIO_NORMALIZATION_TYPE == C.NormalizationType.BOUNDS_Q99:
+        mask = norm_stats.get("mask", np.ones_like(norm_stats["q01"], dtype=bool))
+        high, low = np.array(norm_stats["q99"]), np.array(norm_stats["q01"])
+    else:
+        raise ValueError("Unsupported action/proprio normalization type detected!")
+    return np.clip(np.where(mask, 2 * (proprio - low) / (high - low + 1e-8) - 1, proprio), a_min=-1.0, a_max=1.0)
+
+
+prepare_images_for_vla = image_prep.prepare_images_for_vla
+
+
+def get_vla_action(cfg: Any, vla, processor: Any, obs: Dict[str, Any], task_label: str, action_head=None, proprio_projector=None,
+                   noisy_action_projector=None, use_film: bool = False) -> List[np.ndarray]:
+    """openvla_utils.py:711-796.  Note: like the reference, overwrites obs["state"] with the normalised proprio."""
+    with torch.inference_mode():
+        all_images = [obs["full_image"]]
+        if cfg.num_images_in_input > 1:
+            all_images.extend([obs[k] for k in obs.keys() if "wrist" in k or "camera_gripper_image" in k])
+        all_images = prepare_images_for_vla(all_images, cfg)
+        primary = all_images.pop(0)
+        prompt = f"In: What action should the robot take to {task_label.lower()}?\nOut:"
+        inputs = processor(prompt, primary)
+        if all_images:
+            wrist = [processor(prompt, im)["pixel_values"] for im in all_images]
+            inputs["pixel_values"] = torch.cat([inputs["pixel_values"]] + wrist, dim=1)
+        proprio = None
+        if cfg.use_proprio:
+            obs["state"] = normalize_proprio(obs["state"], vla.norm_stats[cfg.unnorm_key]["proprio"])
+            proprio = obs["state"]
+        if action_head is None:
+            action, _ = vla.predict_action(**inputs, unnorm_key=cfg.unnorm_key, do_sample=False)
+        else:
+            action, _ = vla.predict_action(**inputs, unnorm_key=cfg.unnorm_key, do_sample=False, proprio=proprio,
+                                           proprio_projector=proprio_projector, noisy_action_projector=noisy_action_projector,
+                                           action_head=action_head, use_film=use_film)
+    return [action[i] for i in range(min(len(action), cfg.num_open_loop_steps))]

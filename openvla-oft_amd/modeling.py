@@ -1,0 +1,405 @@
+"""Reference-facing model classes over the HIP engine.
+
+Mirrors the call signatures the LIBERO fine-tune / eval glue uses:
+  OpenVLAForActionPrediction.forward / .predict_action      prismatic/extern/hf/modeling_prismatic.py:499-675, 946-1060
+  L1RegressionActionHead.predict_action                     prismatic/models/action_heads.py:84-107
+  ProprioProjector / NoisyActionProjector                   prismatic/models/projectors.py:6-49
+`forward` returns hidden states that carry a torch autograd edge into the engine's explicit backward, so reference-style
+glue (`loss = L1Loss(gt, head.predict_action(h)); loss.backward()`) works unchanged; the fused training step
+(engine.train_step_fwd_bwd) is what `finetune()` and bench.py use.  All arithmetic runs in libovla_hip.so.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import VLAConfig
+from .engine import ActionHead, MlpProjector, ParamStore, VLAEngine, build_component
+from .weights import make_getter
+
+BF16 = torch.bfloat16
+IGNORE_INDEX = -100
+ACTION_TOKEN_BEGIN_IDX = 31743
+STOP_INDEX = 2
+
+
+def _device(device=None) -> torch.device:
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("openvla-oft_amd runs on MI355X only: there is no CPU / eager fallback for the HIP path")
+    return torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+
+
+# ======================================================================================================================
+# torch-facing parameter views (so `optimizer = AdamW(module.parameters())` style glue keeps working)
+# ======================================================================================================================
+class _StoreModule:
+    """Gives a ParamStore the small part of the nn.Module protocol the reference glue touches."""
+
+    store: ParamStore
+
+    def _torch_params(self):
+        st = self.store
+        if not hasattr(st, "_tparams"):
+            st._tparams = {}
+            st._tgrad = {dt: torch.zeros_like(flat) for dt, flat in st.flat.items()}
+            for p in st.params:
+                tp = nn.Parameter(p.data, requires_grad=True)
+                st._tparams[p.name] = tp
+        return st._tparams
+
+    def parameters(self):
+        return list(self._torch_params().values())
+
+    def named_parameters(self):
+        return list(self._torch_params().items())
+
+    def publish_grads(self):
+        """fp32 accumulators -> `.grad` views in the parameter dtype (what autograd would have produced)."""
+        st = self.store
+        tps = self._torch_params()
+        for dt, g32 in st.flat_grad.items():
+            if dt == BF16:
+                ops.cvt_f32_to_bf16(g32, st._tgrad[dt])
+            else:
+                st._tgrad[dt].copy_(g32)
+        for p in st.params:
+            tps[p.name].grad = st._tgrad[p.dtype][p.offset: p.offset + p.numel].view(p.shape)
+        st._published = True
+
+    def _reset_if_cleared(self):
+        """optimizer.zero_grad() (set_to_none) cleared the published grads -> start a fresh accumulation."""
+        st = self.store
+        if getattr(st, "_published", False) and all(tp.grad is None for tp in self._torch_params().values()):
+            st.zero_grad()
+            st._published = False
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, *a, **k):
+        return self
+
+    @property
+    def module(self):  # DDP-style `.module` access used by the reference glue (finetune.py:398)
+        return self
+
+
+# ======================================================================================================================
+# components
+# ======================================================================================================================
+def _linear_init(out_f, in_f, gen):
+    """nn.Linear default init (kaiming uniform a=sqrt(5) -> U(-1/sqrt(in), 1/sqrt(in)) for weight and bias)."""
+    b = 1.0 / math.sqrt(in_f)
+    return (torch.rand(out_f, in_f, generator=gen) * 2 - 1) * b, (torch.rand(out_f, generator=gen) * 2 - 1) * b
+
+
+class _HeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, head_mod):
+        B = h.shape[0]
+        comp = head_mod.comp
+        pred, _, saved = comp.fwd(h.detach().to(BF16).contiguous().view(-1, h.shape[-1]), train=torch.is_grad_enabled())
+        ctx.saved, ctx.mod, ctx.shape = saved, head_mod, h.shape
+        return pred.view(B, comp.cfg.chunk, comp.cfg.action_dim)
+
+    @staticmethod
+    def backward(ctx, dpred):
+        comp = ctx.mod.comp
+        dah = comp.bwd(ctx.saved, dpred=dpred.to(BF16).contiguous().view(-1, comp.cfg.action_dim))
+        ctx.mod.publish_grads()
+        return dah.view(ctx.shape), None
+
+
+class L1RegressionActionHead(_StoreModule):
+    """prismatic/models/action_heads.py:84-107: MLPResNet(num_blocks=2, input_dim*ACTION_DIM -> hidden -> action_dim)."""
+
+    prefix = "model."
+
+    def __init__(self, input_dim: int = 4096, hidden_dim: int = 4096, action_dim: int = 7, *, num_actions_chunk: int = 8, device=None,
+                 state_dict: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0):
+        if input_dim != hidden_dim:
+            raise ValueError("the reference always builds the head with input_dim == hidden_dim == llm_dim")
+        self.action_dim, self.llm_dim = action_dim, input_dim
+        self.cfg = VLAConfig(llm_dim=input_dim, action_dim=action_dim, chunk=num_actions_chunk)
+        self.device = _device(device)
+        self.training = False
+        sd = state_dict if state_dict is not None else self._default_init(seed)
+        self._build(sd)
+
+    def _default_init(self, seed):
+        g = torch.Generator().manual_seed(seed)
+        D, A, p = self.llm_dim, self.action_dim, self.prefix
+        sd = {}
+        for name, dim in (("layer_norm1", D * A), ("layer_norm2", D), ("mlp_resnet_blocks.0.ffn.0", D), ("mlp_resnet_blocks.1.ffn.0", D)):
+            sd[p + name + ".weight"], sd[p + name + ".bias"] = torch.ones(dim), torch.zeros(dim)
+        for name, o, i in (("fc1", D, D * A), ("mlp_resnet_blocks.0.ffn.1", D, D), ("mlp_resnet_blocks.1.ffn.1", D, D), ("fc2", A, D)):
+            sd[p + name + ".weight"], sd[p + name + ".bias"] = _linear_init(o, i, g)
+        return sd
+
+    def _build(self, sd):
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}   # DDP prefix tolerance (finetune.py:134-156)
+        get, _ = make_getter(sd, self.device)
+        self.comp = build_component(ActionHead, self.device, get, self.prefix, cfg=self.cfg)
+        self.store = self.comp.store
+
+    def predict_action(self, actions_hidden_states: torch.Tensor) -> torch.Tensor:
+        """(B, chunk*action_dim, D) -> (B, chunk, action_dim) bf16."""
+        self._reset_if_cleared()
+        if torch.is_grad_enabled() and actions_hidden_states.requires_grad:
+            return _HeadFn.apply(actions_hidden_states, self)
+        with torch.no_grad():
+            return _HeadFn.apply(actions_hidden_states, self)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        out = {}
+        for lin in self.comp.linears():
+            out.update(lin.export("data"))
+        for p in self.comp.plain_params():
+            out[p.name] = p.data
+        return {k: v.detach().clone() for k, v in out.items()}
+
+    def load_state_dict(self, sd):
+        self._build(sd)
+
+
+class ProprioProjector(_StoreModule):
+    """prismatic/models/projectors.py:6-24 (fp32 parameters, bf16 compute: finetune.py:895-901 never casts it)."""
+
+    prefix = ""
+
+    def __init__(self, llm_dim: int, proprio_dim: int, *, device=None, state_dict=None, seed: int = 0):
+        self.llm_dim, self.in_dim = llm_dim, proprio_dim
+        self.device = _device(device)
+        self.training = False
+        if state_dict is None:
+            g = torch.Generator().manual_seed(seed)
+            state_dict = {}
+            state_dict["fc1.weight"], state_dict["fc1.bias"] = _linear_init(llm_dim, proprio_dim, g)
+            state_dict["fc2.weight"], state_dict["fc2.bias"] = _linear_init(llm_dim, llm_dim, g)
+        self.load_state_dict(state_dict)
+
+    def load_state_dict(self, sd):
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in sd.items()}
+        raw = lambda name: sd[name].detach().to(self.device, torch.float32)   # keep fp32 masters exact
+        self.comp = build_component(MlpProjector, self.device, raw, self.prefix)
+        self.store = self.comp.store
+
+    def state_dict(self):
+        out = {}
+        for lin in self.comp.linears():
+            out.update(lin.export("data"))
+        return {k: v.detach().clone() for k, v in out.items()}
+
+
+class NoisyActionProjector(ProprioProjector):
+    """prismatic/models/projectors.py:27-49"""
+
+    def __init__(self, llm_dim: int, *, device=None, state_dict=None, seed: int = 0):
+        super().__init__(llm_dim, 1, device=device, state_dict=state_dict, seed=seed)
+
+
+# ======================================================================================================================
+# the VLA
+# ======================================================================================================================
+@dataclass
+class PrismaticCausalLMOutputWithPast:
+    """prismatic/extern/hf/modeling_prismatic.py:266-278"""
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Any = None
+    hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
+    attentions: Any = None
+    projector_features: Optional[torch.Tensor] = None
+
+
+class _VisionBackboneHandle:
+    """vla.vision_backbone.{get_num_patches, get_num_images_in_input, set_num_images_in_input} (modeling_prismatic.py:159-184)"""
+
+    def __init__(self, cfg: VLAConfig):
+        self._cfg = cfg
+        self.num_images_in_input = cfg.num_images
+
+    def get_num_patches(self) -> int:
+        return self._cfg.dino.n_patches
+
+    def get_num_images_in_input(self) -> int:
+        return self.num_images_in_input
+
+    def set_num_images_in_input(self, n: int) -> None:
+        self.num_images_in_input = n
+
+
+class _VLMFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, vla, kwargs):
+        out = vla.engine.forward(train=torch.is_grad_enabled(), **kwargs)
+        ctx.vla, ctx.saved = vla, out["saved"]
+        ctx.mark_non_differentiable(out["action_rows"])
+        vla._last = out
+        return out["hidden"], out["action_rows"]
+
+    @staticmethod
+    def backward(ctx, dhidden, _):
+        eng = ctx.vla.engine
+        B, S, D = dhidden.shape
+        eng.backward_from_hidden(dhidden.to(BF16).contiguous().view(B * S, D), ctx.saved)
+        ctx.vla.publish_grads()
+        pp = ctx.saved[8]
+        if pp is not None and hasattr(pp, "owner"):
+            pp.owner.publish_grads()
+        return None, None, None
+
+
+class OpenVLAForActionPrediction(_StoreModule):
+    """prismatic/extern/hf/modeling_prismatic.py:720-1087 over the HIP engine."""
+
+    def __init__(self, cfg: VLAConfig, state_dict: Dict[str, torch.Tensor], *, device=None, lora: Optional[bool] = None,
+                 norm_stats: Optional[dict] = None):
+        self.cfg = cfg
+        self.device = _device(device)
+        get, has = make_getter(state_dict, self.device)
+        if lora is None:
+            lora = any(k.endswith(".lora_A.weight") for k in state_dict)
+        self.engine = VLAEngine(cfg, get, self.device, lora=lora, use_proprio=False, head="none", has=has)
+        self.store = self.engine.store
+        self.llm_dim = cfg.llm_dim
+        self.norm_stats = norm_stats or {}
+        self.bins = np.linspace(-1, 1, cfg.n_action_bins)                       # :725-729
+        self.bin_centers = (self.bins[:-1] + self.bins[1:]) / 2.0
+        self.vocab_size = cfg.vocab - cfg.pad_to_multiple_of                    # :732
+        self.vision_backbone = _VisionBackboneHandle(cfg)
+        self.config = type("Cfg", (), {"image_sizes": [cfg.dino.image_size, cfg.siglip.image_size], "pad_token_id": cfg.pad_token_id})()
+        self.training = False
+        self._anchor = torch.zeros((), device=self.device, requires_grad=True)
+
+    # -- forward (:499-675) -------------------------------------------------------------------------------------------
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    def forward(self, input_ids=None, attention_mask=None, pixel_values=None, labels=None, inputs_embeds=None, past_key_values=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, output_projector_features=None, return_dict=None,
+                proprio=None, proprio_projector=None, noisy_actions=None, noisy_action_projector=None,
+                diffusion_timestep_embeddings=None, use_film: bool = False):
+        if input_ids is None or pixel_values is None or labels is None:
+            raise ValueError("Invalid PrismaticForConditionalGeneration `forward()` call: the HIP path implements the multimodal "
+                             "action-prediction branch (input_ids, pixel_values and labels are required)")
+        if input_ids.shape[0] != pixel_values.shape[0]:
+            raise ValueError("Non-homogenous batch of (text, image) input -- forward() does not support mixed batches!")
+        if past_key_values is not None or inputs_embeds is not None:
+            raise ValueError("cached generation / inputs_embeds are not part of the parallel-decoding action path")
+        if use_film:
+            raise NotImplementedError("FiLM is not built yet in this port (SURVEY.md section 8, config 5)")
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids, dtype=torch.bool)
+        self._reset_if_cleared()
+        for m in (proprio_projector,):
+            if m is not None:
+                m._reset_if_cleared()
+                m.comp.owner = m
+        kwargs = dict(input_ids=input_ids, attention_mask=attention_mask, pixel_values=pixel_values, labels=labels, proprio=proprio,
+                      noisy_actions=noisy_actions, timestep_emb=diffusion_timestep_embeddings,
+                      proprio_projector=None if proprio_projector is None else proprio_projector.comp,
+                      noisy_action_projector=None if noisy_action_projector is None else noisy_action_projector.comp)
+        if torch.is_grad_enabled():
+            hidden, _ = _VLMFn.apply(self._anchor, self, kwargs)
+        else:
+            with torch.no_grad():
+                hidden, _ = _VLMFn.apply(self._anchor, self, kwargs)
+        # the reference also returns the CE loss / fp32 logits of the frozen lm_head; in L1 / diffusion mode they are
+        # discarded (finetune.py:400,407), so they are produced lazily only for the discrete path (see `logits_for`)
+        return PrismaticCausalLMOutputWithPast(loss=None, logits=None, hidden_states=(hidden,), projector_features=None)
+
+    def logits_for(self, hidden_rows: torch.Tensor) -> torch.Tensor:
+        """lm_head on selected hidden rows [n, D] -> fp32 logits [n, vocab] (discrete action-token path, :929-942)."""
+        if self.engine.lm_head is None:
+            raise RuntimeError("this checkpoint was loaded without language_model.lm_head.weight")
+        n = hidden_rows.shape[0]
+        pad = (n + 7) // 8 * 8
+        rows = torch.zeros((pad, self.cfg.llm_dim), dtype=BF16, device=self.device)
+        rows[:n] = hidden_rows
+        return ops.cvt_bf16_to_f32(ops.gemm(rows, self.engine.lm_head))[:n]
+
+    # -- predict_action (:946-1060) -------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def predict_action(self, input_ids=None, unnorm_key=None, proprio=None, proprio_projector=None, action_head=None,
+                       noisy_action_projector=None, use_film: bool = False, **kwargs):
+        cfg = self.cfg
+        A = cfg.num_action_tokens
+        assert input_ids.shape[0] == 1, "Generation is only currently supported for batch size of 1!"
+        pixel_values, attention_mask = kwargs["pixel_values"], kwargs["attention_mask"]
+        input_ids = input_ids.to("cpu", torch.int64)
+        attention_mask = attention_mask.to("cpu")
+        if not torch.all(input_ids[:, -1] == 29871):                                      # :974-977
+            input_ids = torch.cat((input_ids, torch.tensor([[29871]], dtype=torch.int64)), dim=1)
+            attention_mask = torch.cat((attention_mask, torch.ones((1, 1), dtype=attention_mask.dtype)), dim=1)
+        ids = torch.cat([input_ids, torch.ones((1, A), dtype=torch.int64), torch.full((1, 1), STOP_INDEX, dtype=torch.int64)], dim=-1)
+        mask = torch.cat([attention_mask, torch.ones((1, A + 1), dtype=attention_mask.dtype)], dim=-1)
+        labels = torch.full_like(ids, IGNORE_INDEX)                                      # :983-993
+        labels[:, input_ids.shape[-1]:] = ACTION_TOKEN_BEGIN_IDX + 1
+        labels[:, -1] = STOP_INDEX
+        if noisy_action_projector is not None and hasattr(action_head, "noise_scheduler"):
+            raise NotImplementedError("diffusion sampling is not built yet in this port (SURVEY.md section 8, row a11)")
+        use_proprio = proprio_projector is not None and proprio is not None
+        prop = torch.as_tensor(np.asarray(proprio), dtype=torch.float32) if use_proprio else None
+        out = self.engine.forward(ids, mask, pixel_values, labels, proprio=prop, train=False,
+                                  proprio_projector=proprio_projector.comp if use_proprio else None)
+        ah, _ = self.engine.gather_action_hidden(out["hidden"], out["action_rows"])       # rows P+NPT .. P+NPT+A-1 (:915-920)
+        actions_hidden_states = ah.view(1, A, cfg.llm_dim)
+        if action_head is not None:                                                       # :923-927
+            normalized = action_head.predict_action(actions_hidden_states).reshape(cfg.chunk, cfg.action_dim).float().cpu().numpy()
+        else:                                                                             # :929-942
+            tok = self.logits_for(ah).argmax(dim=1).cpu().numpy()
+            d = np.clip(self.vocab_size - tok - 1, a_min=0, a_max=self.bin_centers.shape[0] - 1)
+            normalized = self.bin_centers[d].reshape(cfg.chunk, cfg.action_dim)
+        return self._unnormalize_actions(normalized, unnorm_key), actions_hidden_states
+
+    # -- statistics (:772-791, :1062-1087) -------------------------------------------------------------------------------
+    @staticmethod
+    def _check_unnorm_key(norm_stats, unnorm_key):
+        if unnorm_key is None:
+            assert len(norm_stats) == 1, (
+                f"Your model was trained on more than one dataset, please pass a `unnorm_key` from the following options to choose the "
+                f"statistics used for un-normalizing actions: {norm_stats.keys()}")
+            unnorm_key = next(iter(norm_stats.keys()))
+        assert unnorm_key in norm_stats, (
+            f"The `unnorm_key` you chose is not in the set of available dataset statistics, please choose from: {norm_stats.keys()}")
+        return unnorm_key
+
+    def get_action_dim(self, unnorm_key=None) -> int:
+        return len(self.norm_stats[self._check_unnorm_key(self.norm_stats, unnorm_key)]["action"]["min"])
+
+    def get_action_stats(self, unnorm_key=None):
+        return self.norm_stats[self._check_unnorm_key(self.norm_stats, unnorm_key)]["action"]
+
+    def _unnormalize_actions(self, normalized_actions, unnorm_key=None):
+        stats = self.get_action_stats(unnorm_key)
+        if self.cfg.norm_type == "bounds":
+            mask = stats.get("mask", np.ones_like(stats["min"], dtype=bool))
+            high, low = np.array(stats["max"]), np.array(stats["min"])
+        elif self.cfg.norm_type == "bounds_q99":
+            mask = stats.get("mask", np.ones_like(stats["q01"], dtype=bool))
+            high, low = np.array(stats["q99"]), np.array(stats["q01"])
+        else:
+            raise ValueError("Unsupported action/proprio normalization type detected!")
+        return np.where(mask, 0.5 * (normalized_actions + 1) * (high - low + 1e-8) + low, normalized_actions)
+
+    # -- checkpoint surface --------------------------------------------------------------------------------------------
+    def lora_state_dict(self) -> Dict[str, torch.Tensor]:
+        """LoRA adapters under `<linear>.lora_A.weight` / `.lora_B.weight` (peft adds `base_model.model.` + `.default`)."""
+        out = {}
+        for lin in self.engine.vlm_linears():
+            out.update(lin.export("data"))
+        return {k: v.detach().clone() for k, v in out.items()}

@@ -363,12 +363,14 @@ def head_out_fwd(x, W, b, target=None, loss_sum=None, mse=False):
     return pred
 
 
-def head_out_bwd(x, W, pred, target, dloss_scale, dW, db, mse=False):
+def head_out_bwd(x, W, pred, target, dloss_scale, dW, db, mse=False, dpred=None):
+    """Backward of the head tail.  Either (pred, target, dloss_scale) -- fused L1/MSE gradient -- or an explicit dpred."""
     rows, dim = x.shape
     adim = W.shape[0]
     dx = torch.empty_like(x)
     g = STRUCTS["ovla_head_out_bwd_args"]()
-    g.x, g.W, g.pred, g.target, g.dloss_scale, g.mse = x.data_ptr(), W.data_ptr(), pred.data_ptr(), target.data_ptr(), dloss_scale, int(mse)
+    g.x, g.W, g.pred, g.target, g.dpred = x.data_ptr(), W.data_ptr(), _p(pred), _p(target), _p(dpred)
+    g.dloss_scale, g.mse = dloss_scale, int(mse)
     g.dx, g.dW, g.db, g.rows, g.dim, g.adim = dx.data_ptr(), _p(dW), _p(db), rows, dim, adim
     _lib.call("ovla_head_out_bwd", g, _stream())
     return dx

@@ -1,0 +1,222 @@
+"""LoRA fine-tune driver (mirror of vla-scripts/finetune.py: FinetuneConfig :79-131, run_forward_pass :280-451,
+save_training_checkpoint :584-675, finetune :763-1154) on the HIP engine.
+
+  torchrun --standalone --nnodes 1 --nproc-per-node N -m ...   (one process per GPU, RCCL through torch.distributed)
+
+What differs from the reference, deliberately:
+  * the optimisation step runs the engine's fused path: explicit forward/backward kernels, gradients accumulated in flat
+    fp32 buffers, one fused AdamW launch per dtype (same arithmetic as torch.optim.AdamW on bf16 / fp32 parameters), one
+    large RCCL all-reduce per bucket instead of four DDP wrappers;
+  * the frozen lm_head + cross-entropy the reference computes and discards in L1 mode is not executed;
+  * the data source is pluggable: `dataset` is any iterable of collated batches (prismatic/util/data_utils.py:102-156
+    layout).  The TF/RLDS pipeline is out of scope; without one, seeded synthetic
+    LIBERO-shaped batches are used (`synthetic.make_batch`).
+`run_forward_pass` keeps the reference signature and works through torch autograd for glue that wants it.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Dict, Iterable, Optional, Tuple
+
+import torch
+
+from .. import synthetic
+from ..config import OPENVLA_7B, VLAConfig
+from ..dp import GradReducer
+from ..engine import VLAEngine
+from ..prismatic.training.train_utils import get_current_action_mask, get_next_actions_mask
+from ..prismatic.vla import constants as C
+from ..weights import make_getter, random_state_dict
+
+
+@dataclass
+class FinetuneConfig:
+    # fmt: off
+    vla_path: str = "openvla/openvla-7b"
+    data_root_dir: Path = Path("datasets/rlds")
+    dataset_name: str = "aloha_scoop_x_into_bowl"
+    run_root_dir: Path = Path("runs")
+    shuffle_buffer_size: int = 100_000
+    use_l1_regression: bool = True
+    use_diffusion: bool = False
+    num_diffusion_steps: int = 50
+    use_film: bool = False
+    num_images_in_input: int = 1
+    use_proprio: bool = False
+    batch_size: int = 8
+    learning_rate: float = 5e-4
+    lr_warmup_steps: int = 0
+    num_steps_before_decay: int = 100_000
+    grad_accumulation_steps: int = 1
+    max_steps: int = 200_000
+    use_val_set: bool = False
+    val_freq: int = 10_000
+    val_time_limit: int = 180
+    save_freq: int = 10_000
+    save_latest_checkpoint_only: bool = False
+    resume: bool = False
+    resume_step: Optional[int] = None
+    image_aug: bool = True
+    diffusion_sample_freq: int = 50
+    use_lora: bool = True
+    lora_rank: int = 32
+    lora_dropout: float = 0.0
+    merge_lora_during_training: bool = True
+    wandb_entity: str = "your-wandb-entity"
+    wandb_project: str = "your-wandb-project"
+    run_id_note: Optional[str] = None
+    run_id_override: Optional[str] = None
+    wandb_log_freq: int = 10
+    # fmt: on
+
+
+def remove_ddp_in_checkpoint(state_dict) -> dict:
+    """finetune.py:134-156"""
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+
+
+def get_run_id(cfg) -> str:
+    """finetune.py:159-190"""
+    if cfg.run_id_override is not None:
+        return cfg.run_id_override
+    if cfg.resume:
+        run_id = cfg.vla_path.split("/")[-1]
+        if "chkpt" in run_id.split("--")[-1]:
+            run_id = "--".join(run_id.split("--")[:-1])
+        return run_id
+    run_id = f"{cfg.vla_path.split('/')[-1]}+{cfg.dataset_name}+b{cfg.batch_size * cfg.grad_accumulation_steps}+lr-{cfg.learning_rate}"
+    if cfg.use_lora:
+        run_id += f"+lora-r{cfg.lora_rank}+dropout-{cfg.lora_dropout}"
+    if cfg.image_aug:
+        run_id += "--image_aug"
+    if cfg.run_id_note is not None:
+        run_id += f"--{cfg.run_id_note}"
+    return run_id
+
+
+def learning_rate_at(cfg, gradient_step_idx: int) -> float:
+    """MultiStepLR(milestones=[num_steps_before_decay], gamma=0.1) + optional linear warm-up 10% -> 100%
+    (finetune.py:958-962, 1094-1098).  The step index is the number of optimizer steps already taken."""
+    lr = cfg.learning_rate * (0.1 if gradient_step_idx >= cfg.num_steps_before_decay else 1.0)
+    if cfg.lr_warmup_steps > 0:
+        progress = min((gradient_step_idx + 1) / cfg.lr_warmup_steps, 1.0)
+        lr = cfg.learning_rate * (0.1 + 0.9 * progress)
+    return lr
+
+
+def run_forward_pass(vla, action_head, noisy_action_projector, proprio_projector, batch, action_tokenizer, device_id, use_l1_regression,
+                     use_diffusion, use_proprio, use_film, num_patches, compute_diffusion_l1=False, num_diffusion_steps=None
+                     ) -> Tuple[torch.Tensor, Dict[str, float]]:
+    """finetune.py:280-451 with the reference's signature, L1-regression branch, through the autograd bridge of
+    modeling.py (`loss.backward()` then drives the engine's explicit backward)."""
+    if use_diffusion or not use_l1_regression:
+        raise NotImplementedError("only the L1-regression objective is built in this port so far (SURVEY.md section 8)")
+    metrics = {}
+    gt = batch["actions"].to(device_id).to(torch.bfloat16)
+    output = vla(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], pixel_values=batch["pixel_values"], labels=batch["labels"],
+                 output_hidden_states=True, proprio=batch["proprio"] if use_proprio else None,
+                 proprio_projector=proprio_projector if use_proprio else None, use_film=use_film)
+    ids = batch["labels"][:, 1:].to(device_id)
+    cur, nxt = get_current_action_mask(ids), get_next_actions_mask(ids)
+    last = output.hidden_states[-1]
+    text_hidden = last[:, num_patches:-1]
+    B = batch["input_ids"].shape[0]
+    ah = text_hidden[cur | nxt].reshape(B, C.NUM_ACTIONS_CHUNK * C.ACTION_DIM, -1).to(torch.bfloat16)
+    pred = action_head.module.predict_action(ah)
+    loss = torch.nn.L1Loss()(gt, pred)
+    metrics["loss_value"] = loss.item()
+    metrics["curr_action_l1_loss"] = torch.nn.L1Loss()(gt[:, 0], pred[:, 0]).item()
+    metrics["next_actions_l1_loss"] = torch.nn.L1Loss()(gt[:, 1:], pred[:, 1:]).item()
+    return loss, metrics
+
+
+def save_training_checkpoint(run_dir: Path, log_step: int, engine: VLAEngine, dataset_statistics: Optional[dict], rank: int,
+                             latest_only: bool = False) -> Path:
+    """finetune.py:584-675: `{component}--{step}_checkpoint.pt` (+ `lora_adapter/`, `dataset_statistics.json`).
+    The LoRA merge of the reference (:663-675) is a separate offline step here (W += scale * B A per adapted Linear)."""
+    ckpt = run_dir if latest_only else Path(str(run_dir) + f"--{log_step}_chkpt")
+    suffix = "latest_checkpoint.pt" if latest_only else f"{log_step}_checkpoint.pt"
+    if rank == 0:
+        (ckpt / "lora_adapter").mkdir(parents=True, exist_ok=True)
+        if dataset_statistics is not None:
+            (ckpt / "dataset_statistics.json").write_text(json.dumps(dataset_statistics))
+        exp = {k: v.detach().to("cpu") for k, v in engine.export_trainable("data").items()}
+        from safetensors.torch import save_file
+
+        save_file({k: v.contiguous() for k, v in exp.items() if ".lora_" in k}, str(ckpt / "lora_adapter" / "adapter_model.safetensors"))
+        groups = {"proprio_projector": "proprio_projector.", "noisy_action_projector": "noisy_action_projector.", "action_head": "action_head."}
+        for comp, prefix in groups.items():
+            sd = {k[len(prefix):]: v.contiguous() for k, v in exp.items() if k.startswith(prefix)}
+            if sd:
+                torch.save(sd, ckpt / f"{comp}--{suffix}")
+    return ckpt
+
+
+def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state_dict: Optional[Dict[str, torch.Tensor]] = None,
+             dataset: Optional[Iterable[dict]] = None, dataset_statistics: Optional[dict] = None, log=print) -> Dict[str, list]:
+    """finetune.py:763-1154.  Returns the logged metric history."""
+    assert cfg.use_lora, "Only LoRA fine-tuning is supported. Please set --use_lora=True!"
+    assert not (cfg.use_l1_regression and cfg.use_diffusion), "Cannot do both L1 regression and diffusion. Please pick one of them!"
+    if cfg.use_diffusion or cfg.use_film or not cfg.use_l1_regression:
+        raise NotImplementedError("this port builds the L1-regression recipe (LIBERO.md:91-115); diffusion / FiLM are later SURVEY section 8 rows")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group("nccl", device_id=dev)
+    run_dir = cfg.run_root_dir / get_run_id(cfg)
+    if rank == 0:
+        os.makedirs(run_dir, exist_ok=True)
+    model_config = VLAConfig(**{**model_config.__dict__, "num_images": cfg.num_images_in_input, "lora_rank": cfg.lora_rank,
+                                "lora_alpha": min(cfg.lora_rank, 16), "action_dim": C.ACTION_DIM, "chunk": C.NUM_ACTIONS_CHUNK,
+                                "proprio_dim": C.PROPRIO_DIM, "norm_type": C.ACTION_PROPRIO_NORMALIZATION_TYPE.value})
+    if state_dict is None:
+        log(f"[finetune] no checkpoint at `{cfg.vla_path}` is loadable offline: using seeded random weights of the architecture")
+        state_dict = random_state_dict(model_config, dev, seed=0, lm_head=False)
+    get, has = make_getter(state_dict, dev)
+    engine = VLAEngine(model_config, get, dev, lora=True, use_proprio=cfg.use_proprio, head="l1", has=has)
+    log(f"# total trainable params: {engine.num_trainable()}")
+    reducer = GradReducer(engine.stores, world) if world > 1 else None
+    if dataset is None:
+        def synthetic_stream():
+            step = 0
+            while True:
+                yield synthetic.make_batch(cfg.batch_size, seed=1000 * (step + 1) + rank, num_images=cfg.num_images_in_input,
+                                           chunk=C.NUM_ACTIONS_CHUNK, action_dim=C.ACTION_DIM, proprio_dim=C.PROPRIO_DIM,
+                                           image_size=model_config.dino.image_size)
+                step += 1
+        dataset = synthetic_stream()
+    history = {"loss_value": [], "learning_rate": []}
+    engine.zero_grad()
+    for batch_idx, batch in enumerate(dataset):
+        if not cfg.use_proprio:
+            batch = {**batch, "proprio": None}
+        loss_sum, count, _ = engine.train_step_fwd_bwd(batch, loss_scale=1.0 / cfg.grad_accumulation_steps)
+        gradient_step_idx = batch_idx // cfg.grad_accumulation_steps
+        log_step = gradient_step_idx if not cfg.resume else cfg.resume_step + gradient_step_idx
+        if (batch_idx + 1) % cfg.grad_accumulation_steps == 0:
+            if reducer is not None:
+                reducer.all_reduce()
+            lr = learning_rate_at(cfg, gradient_step_idx)
+            engine.adamw_step(lr, grad_scale=1.0 / world)
+            engine.refresh_derived()
+            engine.zero_grad()
+            if log_step % cfg.wandb_log_freq == 0:
+                history["loss_value"].append(loss_sum.item() / count)
+                history["learning_rate"].append(lr)
+                if rank == 0:
+                    log(f"step {log_step}: loss {history['loss_value'][-1]:.5f} lr {lr:.2e}")
+            if gradient_step_idx > 0 and log_step % cfg.save_freq == 0:
+                save_training_checkpoint(run_dir, log_step, engine, dataset_statistics, rank, cfg.save_latest_checkpoint_only)
+                if world > 1:
+                    dist.barrier()
+            if log_step + 1 >= cfg.max_steps:
+                break
+    return history

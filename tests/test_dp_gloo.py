@@ -1,0 +1,57 @@
+"""Multi-process (world_size 2, gloo, CPU) test of the data-parallel gradient exchange: GradReducer sums the flat
+gradient buckets across ranks; with grad_scale = 1/world in the optimizer this is DDP's gradient averaging
+(vla-scripts/finetune.py:212-224)."""
+import importlib
+import os
+import socket
+import sys
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _Store:
+    def __init__(self, rank):
+        g = torch.Generator().manual_seed(100 + rank)
+        self.flat_grad = {torch.bfloat16: torch.randn(1000, generator=g), torch.float32: torch.randn(333, generator=g)}
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dp = importlib.import_module("openvla-oft_amd.dp")
+    stores = [_Store(rank), _Store(rank + 10)]
+    red = dp.GradReducer(stores, world, bucket_bytes=1024)      # force several buckets per buffer
+    assert len(list(red.buckets())) > 8
+    red.all_reduce()
+    torch.save([{str(k): v for k, v in s.flat_grad.items()} for s in stores], f"{out}/rank{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in (0, 1))
+    for si, base in enumerate((0, 10)):
+        expect = {str(k): _Store(0 + base).flat_grad[k] + _Store(1 + base).flat_grad[k] for k in (torch.bfloat16, torch.float32)}
+        for k, v in expect.items():
+            assert torch.allclose(r0[si][k], v) and torch.equal(r0[si][k], r1[si][k]), k
+
+
+def test_single_rank_is_a_no_op():
+    dp = importlib.import_module("openvla-oft_amd.dp")
+    s = _Store(0)
+    before = {k: v.clone() for k, v in s.flat_grad.items()}
+    dp.GradReducer([s], 1).all_reduce()
+    assert all(torch.equal(before[k], s.flat_grad[k]) for k in before)

@@ -92,7 +92,7 @@ def test_backward_matches_oracle_autograd(setup):
     sde = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
     le, _, _ = vo.Oracle(ocfg, sde, mode="bf16").train_forward(batch)
     le.backward()
-    eng.store.zero_grad()
+    eng.zero_grad()
     loss_sum, count, _ = eng.train_step_fwd_bwd(batch)
     assert abs(loss_sum.item() / count - loss.item()) < 2e-2 * max(1.0, abs(loss.item()))
     grads = eng.export_trainable("grad")
@@ -120,9 +120,9 @@ def test_optimizer_step_moves_toward_lower_loss(setup):
     eng, batch = setup["eng"], setup["batch"]
     losses = []
     for _ in range(4):
-        eng.store.zero_grad()
+        eng.zero_grad()
         loss_sum, count, _ = eng.train_step_fwd_bwd(batch)
-        eng.store.adamw_step(lr=5e-4)
+        eng.adamw_step(lr=5e-4)
         eng.refresh_derived()
         losses.append(loss_sum.item() / count)
     print("losses", losses)
