@@ -98,6 +98,10 @@ def lib() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             f"(or {_PKG_DIR / 'csrc' / 'build.sh'}). There is no fallback path."
         )
+    # PyTorch-ROCm ships its own libamdhip64; it must be the first HIP runtime mapped into the process, otherwise torch
+    # later finds "No HIP GPUs".  Importing torch first makes our library bind to the runtime torch uses (same soname).
+    import torch  # noqa: F401
+
     handle = ctypes.CDLL(str(LIB_PATH), mode=getattr(os, "RTLD_NOW", 2))
     for name, (ret, argtypes) in FUNCTIONS.items():
         fn = getattr(handle, name)  # AttributeError if the .so does not export a declared symbol

@@ -108,10 +108,10 @@ def _linear_init(out_f, in_f, gen):
 
 class _HeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, h, head_mod):
+    def forward(ctx, h, head_mod, train):
         B = h.shape[0]
         comp = head_mod.comp
-        pred, _, saved = comp.fwd(h.detach().to(BF16).contiguous().view(-1, h.shape[-1]), train=torch.is_grad_enabled())
+        pred, _, saved = comp.fwd(h.detach().to(BF16).contiguous().view(-1, h.shape[-1]), train=train)
         ctx.saved, ctx.mod, ctx.shape = saved, head_mod, h.shape
         return pred.view(B, comp.cfg.chunk, comp.cfg.action_dim)
 
@@ -120,7 +120,7 @@ class _HeadFn(torch.autograd.Function):
         comp = ctx.mod.comp
         dah = comp.bwd(ctx.saved, dpred=dpred.to(BF16).contiguous().view(-1, comp.cfg.action_dim))
         ctx.mod.publish_grads()
-        return dah.view(ctx.shape), None
+        return dah.view(ctx.shape), None, None
 
 
 class L1RegressionActionHead(_StoreModule):
@@ -159,9 +159,9 @@ class L1RegressionActionHead(_StoreModule):
         """(B, chunk*action_dim, D) -> (B, chunk, action_dim) bf16."""
         self._reset_if_cleared()
         if torch.is_grad_enabled() and actions_hidden_states.requires_grad:
-            return _HeadFn.apply(actions_hidden_states, self)
+            return _HeadFn.apply(actions_hidden_states, self, True)
         with torch.no_grad():
-            return _HeadFn.apply(actions_hidden_states, self)
+            return _HeadFn.apply(actions_hidden_states, self, False)
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         out = {}
@@ -244,8 +244,8 @@ class _VisionBackboneHandle:
 
 class _VLMFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchor, vla, kwargs):
-        out = vla.engine.forward(train=torch.is_grad_enabled(), **kwargs)
+    def forward(ctx, anchor, vla, kwargs, train):
+        out = vla.engine.forward(train=train, **kwargs)
         ctx.vla, ctx.saved = vla, out["saved"]
         ctx.mark_non_differentiable(out["action_rows"])
         vla._last = out
@@ -260,7 +260,7 @@ class _VLMFn(torch.autograd.Function):
         pp = ctx.saved[8]
         if pp is not None and hasattr(pp, "owner"):
             pp.owner.publish_grads()
-        return None, None, None
+        return None, None, None, None
 
 
 class OpenVLAForActionPrediction(_StoreModule):
@@ -314,10 +314,10 @@ class OpenVLAForActionPrediction(_StoreModule):
                       proprio_projector=None if proprio_projector is None else proprio_projector.comp,
                       noisy_action_projector=None if noisy_action_projector is None else noisy_action_projector.comp)
         if torch.is_grad_enabled():
-            hidden, _ = _VLMFn.apply(self._anchor, self, kwargs)
+            hidden, _ = _VLMFn.apply(self._anchor, self, kwargs, True)
         else:
             with torch.no_grad():
-                hidden, _ = _VLMFn.apply(self._anchor, self, kwargs)
+                hidden, _ = _VLMFn.apply(self._anchor, self, kwargs, False)
         # the reference also returns the CE loss / fp32 logits of the frozen lm_head; in L1 / diffusion mode they are
         # discarded (finetune.py:400,407), so they are produced lazily only for the discrete path (see `logits_for`)
         return PrismaticCausalLMOutputWithPast(loss=None, logits=None, hidden_states=(hidden,), projector_features=None)
