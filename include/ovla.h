@@ -74,6 +74,8 @@ typedef struct {
   int32_t film_rows;
   int32_t M, N, K, K2;
   int32_t k2_group_n;            /* 0: A2 column offset 0 for every tile */
+  int32_t a_group_n;             /* >0: block-diagonal GEMM -- output columns [g*a_group_n, (g+1)*a_group_n) contract A columns
+                                    [g*K, (g+1)*K) with B rows of the same column range (per-group LoRA dt = dy_g . B_g) */
   int32_t act;
   int32_t split_k;               /* <=1: none */
   int32_t tile;                  /* 0: auto; otherwise forces a tile configuration (tests / tuning) */
@@ -101,6 +103,10 @@ typedef struct {
   int32_t out_mode;
 } ovla_gemm_tn_args;
 int ovla_gemm_tn_bf16(const ovla_gemm_tn_args* a, void* stream);
+/* Up to OVLA_TN_MAX_GROUP independent TN problems in ONE launch (the dA / dB_g products of one LoRA linear): the small
+ * problems then overlap on the chip instead of running back to back. */
+#define OVLA_TN_MAX_GROUP 4
+int ovla_gemm_tn_grouped(const ovla_gemm_tn_args* problems, int32_t n, void* stream);
 
 /* column sums  out[n] (+)= sum_m X[m,n]   (bias gradients).  out fp32, atomic accumulate. */
 typedef struct { const void* X; int64_t ldx; float* out; int32_t M, N; } ovla_colsum_args;
@@ -290,6 +296,9 @@ int ovla_cvt_bf16_to_f32(const void* src, float* dst, int64_t n, float scale, vo
 /* transpose bf16 [rows, cols] -> [cols, rows] (W^T copies of the frozen weights, LoRA A^T/B^T refresh) */
 typedef struct { const void* src; void* dst; int32_t rows, cols; int64_t lds, ldd; } ovla_transpose_args;
 int ovla_transpose_bf16(const ovla_transpose_args* a, void* stream);
+/* Many transposes in one launch: `table` is a DEVICE array of n ovla_transpose_args (built once: the LoRA factors and
+ * their derived A^T / B^T copies never move), max_rows / max_cols bound the largest entry. */
+int ovla_transpose_batched(const ovla_transpose_args* table, int32_t n, int32_t max_rows, int32_t max_cols, void* stream);
 
 /* self-test hook used by tests/: dumps the MFMA / transposed-LDS-read / LDS-DMA lane layouts the kernels rely on.
  * out: fp32 [4, 64, 16] device;  src: bf16 [512] device holding 0..511. */

@@ -437,6 +437,25 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_bits* __restr
   }
 }
 
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const ovla_transpose_args* __restrict__ table, int tiles_x) {
+  __shared__ bf16_bits tile[64][66];
+  const ovla_transpose_args d = table[blockIdx.y];
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int r0 = ty * 64, c0 = tx * 64;
+  if (r0 >= d.rows || c0 >= d.cols) return;
+  const bf16_bits* src = (const bf16_bits*)d.src;
+  bf16_bits* dst = (bf16_bits*)d.dst;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < d.rows && c0 + c < d.cols) ? src[(int64_t)(r0 + r) * d.lds + c0 + c] : (bf16_bits)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < d.rows && c0 + c < d.cols) dst[(int64_t)(c0 + c) * d.ldd + r0 + r] = tile[r][c];
+  }
+}
+
 // column sums: out[n] += sum_m X[m,n]; grid (N/64 col blocks, row chunks)
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_bits* __restrict__ X, int64_t ldx, float* __restrict__ out, int M,
                                                      int N, int rows_per_block) {
@@ -635,6 +654,14 @@ extern "C" int ovla_transpose_bf16(const ovla_transpose_args* a, void* stream_) 
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(a->cols, 64), cdiv(a->rows, 64)), dim3(256), 0, stream, (const bf16_bits*)a->src,
                      (bf16_bits*)a->dst, a->rows, a->cols, a->lds, a->ldd);
   OVLA_CHECK_LAUNCH("ovla_transpose_bf16");
+  return OVLA_OK;
+}
+extern "C" int ovla_transpose_batched(const ovla_transpose_args* table, int32_t n, int32_t max_rows, int32_t max_cols, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(table && n > 0 && max_rows > 0 && max_cols > 0, "ovla_transpose_batched: bad arguments");
+  const int tx = cdiv(max_cols, 64), ty = cdiv(max_rows, 64);
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(tx * ty, n), dim3(256), 0, stream, table, tx);
+  OVLA_CHECK_LAUNCH("ovla_transpose_batched");
   return OVLA_OK;
 }
 extern "C" int ovla_colsum_bf16(const ovla_colsum_args* a, void* stream_) {

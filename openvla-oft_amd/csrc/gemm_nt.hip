@@ -32,7 +32,7 @@ struct GemmParams {
   int64_t ldr;
   const bf16_bits *film_gamma, *film_beta;
   int film_rows;
-  int M, N, K, K2, k2_group_n, act, split_k;
+  int M, N, K, K2, k2_group_n, a_group_n, act, split_k;
   float alpha;
   float* ws;
   int tiles_m, tiles_n, T1, T2;
@@ -161,6 +161,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     t_end = t_begin + chunk < T ? t_begin + chunk : T;
   }
   const int a2_col0 = p.k2_group_n > 0 ? (n0 / p.k2_group_n) * p.K2 : 0;
+  const bf16_bits* Ablk = p.A + (p.a_group_n > 0 ? (int64_t)(n0 / p.a_group_n) * p.K : 0);   // block-diagonal: group's A columns
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     bf16_bits* sB = sA + BM * BK;
     if (t < p.T1) {
       const int k0 = t * BK;
-      stage_tile<BM, NW>(p.A, p.lda, m0, p.M - 1, k0, p.K, sA, wave, lane);
+      stage_tile<BM, NW>(Ablk, p.lda, m0, p.M - 1, k0, p.K, sA, wave, lane);
       stage_tile<BN, NW>(p.B, p.ldb, n0, p.N - 1, k0, p.K, sB, wave, lane);
     } else {
       const int k0 = (t - p.T1) * BK;
@@ -190,20 +191,35 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     if (t + 1 < t_end) stage(t + 1, buf ^ 1);
     const bf16_bits* sA = smem + buf * TILE_ELEMS;
     const bf16_bits* sB = sA + BM * BK;
+    // MFMA rows r = (k-substep s, m-tile i).  Fragment reads run one row ahead of the MFMAs: while row r's NT MFMAs
+    // issue, the A fragment of row r+1 and a slice of the NEXT substep's B fragments are in flight, so the two waves
+    // sharing a SIMD do not both sit in an un-overlapped LDS phase after every barrier.
+    constexpr int BPR = (NT + MT - 1) / MT;  // next-substep B fragments fetched per row
+    const int arow = wm * WTM + (lane & 15), brow = wn * WTN + (lane & 15), cq = lane >> 4;
+    bf16x8_bits b0[NT], b1[NT];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8_bits a[MT], b[NT];
-      const int chunk = s * 4 + (lane >> 4);
+    for (int j = 0; j < NT; ++j) b0[j] = lds_frag(sB, brow + j * 16, cq);
+    bf16x8_bits a_cur = lds_frag(sA, arow, cq);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = lds_frag(sA, wm * WTM + i * 16 + (lane & 15), chunk);
+    for (int r = 0; r < 2 * MT; ++r) {
+      const int sub = r / MT, i = r % MT;
+      bf16x8_bits a_nxt = a_cur;
+      if (r + 1 < 2 * MT) a_nxt = lds_frag(sA, arow + ((r + 1) % MT) * 16, ((r + 1) / MT) * 4 + cq);
+      if (sub == 0) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = lds_frag(sB, wn * WTN + j * 16 + (lane & 15), chunk);
+        for (int jj = 0; jj < BPR; ++jj)
+          if (i * BPR + jj < NT) b1[i * BPR + jj] = lds_frag(sB, brow + (i * BPR + jj) * 16, 4 + cq);
+      }
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sub == 0 ? b0[j] : b1[j], a_cur, acc[i][j], 0, 0, 0);
+      if (sub == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1 + BPR, 0);  // DS reads of the next row
+      else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);                       // this row's MFMAs
+      a_cur = a_nxt;
     }
+    __builtin_amdgcn_s_setprio(0);
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
@@ -526,7 +542,7 @@ int launch_cfg(GemmParams& p, hipStream_t stream, int64_t ws_bytes = 0, bool hyb
     static_assert((size_t)WM * WN * 32 * (BN / WN + 4) * sizeof(float) <= 160 * 1024, "epilogue slabs exceed LDS");
     const int slots = num_cus() * bpc;
     const int rem = tiles % slots;
-    if (rem > 0 && rem * 2 <= slots) {
+    if (rem > 0 && rem * 4 <= slots * 3) {
       const double tile_flops = 2.0 * BM * BN * ((double)p.K + p.K2);
       const double per_slot = (BM >= 256 && BN >= 256 ? 1.3e15 : 0.95e15) / slots;
       const int sp = pick_rem_splits(rem, slots, p.T1 + p.T2, tile_flops, per_slot, 4.0 * BM * BN, ws_bytes / 4, BM * BN);
@@ -600,6 +616,11 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   OVLA_REQUIRE((a->lda % 8) == 0 && (a->ldb % 8) == 0 && (a->ldc % 4) == 0, "ovla_gemm_bf16: lda/ldb must be multiples of 8, ldc of 4");
   OVLA_REQUIRE(a->lda >= a->K && a->ldb >= a->K && a->ldc >= a->N, "ovla_gemm_bf16: leading dimension smaller than extent");
   OVLA_REQUIRE(aligned16(a->A) && aligned16(a->B) && (((uintptr_t)a->C) & 7) == 0, "ovla_gemm_bf16: A/B need 16-byte, C 8-byte alignment");
+  if (a->a_group_n > 0) {
+    OVLA_REQUIRE(a->K2 <= 0 && (a->N % a->a_group_n) == 0 && (a->a_group_n == 32 || a->a_group_n % 128 == 0) && a->lda >= (int64_t)(a->N / a->a_group_n) * a->K,
+                 "ovla_gemm_bf16: block-diagonal mode needs N %% a_group_n == 0, a_group_n 32 or a multiple of 128, lda >= groups*K, no K-extension");
+    OVLA_REQUIRE(a->tile == 0 || a->tile == 5 || a->tile == 2 || a->tile == 1, "ovla_gemm_bf16: block-diagonal mode runs on the BK=64 kernel tiles only");
+  }
   if (a->K2 > 0) {
     OVLA_REQUIRE(a->A2 && a->B2, "ovla_gemm_bf16: K2>0 but A2/B2 null");
     OVLA_REQUIRE((a->K2 % 8) == 0 && (a->lda2 % 8) == 0 && (a->ldb2 % 8) == 0, "ovla_gemm_bf16: K2/lda2/ldb2 must be multiples of 8");
@@ -623,7 +644,7 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   p.residual = (const bf16_bits*)a->residual; p.ldr = a->ldr;
   p.film_gamma = (const bf16_bits*)a->film_gamma; p.film_beta = (const bf16_bits*)a->film_beta; p.film_rows = a->film_rows;
   p.M = a->M; p.N = a->N; p.K = a->K; p.K2 = a->K2 > 0 ? a->K2 : 0;
-  p.k2_group_n = a->k2_group_n; p.act = a->act; p.split_k = a->split_k > 1 ? a->split_k : 1;
+  p.k2_group_n = a->k2_group_n; p.a_group_n = a->a_group_n; p.act = a->act; p.split_k = a->split_k > 1 ? a->split_k : 1;
   p.ws = (float*)a->workspace;
   p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
   p.T1 = cdiv(p.K, BK); p.T2 = p.K2 > 0 ? cdiv(p.K2, BK) : 0;
@@ -643,7 +664,8 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
       while (sp < 8 && tiles * sp < 256 && (sp * 2) * 8 <= T && ovla_gemm_workspace_bytes(p.M, p.N, sp * 2) <= wsb) sp *= 2;
       return sp;
     };
-    if (p.N <= 32) { tile = 5; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 128)); }
+    if (p.N <= 32 || p.a_group_n == 32) { tile = 5; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 128) * cdiv(p.N, 32)); }
+    else if (p.a_group_n > 0) { tile = 1; }
     else if (p.M <= 64 || p.N <= 128) { tile = 2; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 64) * cdiv(p.N, 128)); }
     else if ((int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 200 && p.K >= 2048 && (p.k2_group_n == 0 || p.k2_group_n % 256 == 0)) { tile = 17; hybrid = true; }
     else { tile = 1; hybrid = true; }

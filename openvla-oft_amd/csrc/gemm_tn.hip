@@ -64,18 +64,17 @@ struct TnStage {
 };
 
 template <int BP, int BQ, int WP, int WQ>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
+OVLA_DEV void gemm_tn_body(const TnParams& p, bf16_bits* smem, int tile, int msplit) {
   static_assert(WP * WQ == 4, "4 waves");
   constexpr int TP = BP / WP / 32, TQ = BQ / WQ / 32;
   constexpr int SX = TnStage<BP>::STRIDE, SY = TnStage<BQ>::STRIDE;
-  __shared__ __attribute__((aligned(16))) bf16_bits Xs[BMK * SX];
-  __shared__ __attribute__((aligned(16))) bf16_bits Ys[BMK * SY];
+  bf16_bits* Xs = smem;
+  bf16_bits* Ys = smem + BMK * SX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wp = wave / WQ, wq = wave % WQ;
-  const int tile = blockIdx.x;
   const int tp = tile / p.tiles_q, tq = tile % p.tiles_q;
   const int p0 = tp * BP, q0 = tq * BQ;
-  const int m_begin = blockIdx.y * p.m_chunk;
+  const int m_begin = msplit * p.m_chunk;
   const int m_end = (m_begin + p.m_chunk) < p.M ? (m_begin + p.m_chunk) : p.M;
   const int nsteps = (m_end - m_begin + BMK - 1) / BMK;
 
@@ -135,22 +134,70 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
     }
 }
 
+constexpr int TN_LDS_ELEMS = BMK * (128 + 32) * 2;   // largest X + Y tile pair (128x128 config)
+
 template <int BP, int BQ, int WP, int WQ>
-int launch_tn(TnParams& p, hipStream_t stream) {
-  p.tiles_p = cdiv(p.P, BP);
-  p.tiles_q = cdiv(p.Q, BQ);
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_bits smem[TN_LDS_ELEMS];
+  gemm_tn_body<BP, BQ, WP, WQ>(p, smem, blockIdx.x, blockIdx.y);
+}
+
+struct TnGroup {
+  TnParams prob[OVLA_TN_MAX_GROUP];
+  int cfg[OVLA_TN_MAX_GROUP];      // 0: <32,128>  1: <128,32>  2: <128,128>
+  int blocks[OVLA_TN_MAX_GROUP];   // tiles * m-splits of each problem
+  int n;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_grouped_kernel(const TnGroup g) {
+  __shared__ __attribute__((aligned(16))) bf16_bits smem[TN_LDS_ELEMS];
+  int b = blockIdx.x, i = 0;
+  while (i < g.n - 1 && b >= g.blocks[i]) {
+    b -= g.blocks[i];
+    ++i;
+  }
+  const TnParams& p = g.prob[i];
+  const int tiles = p.tiles_p * p.tiles_q;
+  const int tile = b % tiles, msplit = b / tiles;
+  if (g.cfg[i] == 0) gemm_tn_body<32, 128, 1, 4>(p, smem, tile, msplit);
+  else if (g.cfg[i] == 1) gemm_tn_body<128, 32, 4, 1>(p, smem, tile, msplit);
+  else gemm_tn_body<128, 128, 2, 2>(p, smem, tile, msplit);
+}
+
+static int plan_tn(TnParams& p, int bp, int bq, int target_blocks) {
+  p.tiles_p = cdiv(p.P, bp);
+  p.tiles_q = cdiv(p.Q, bq);
   const int tiles = p.tiles_p * p.tiles_q;
   int splits = 1;
   if (p.out_mode == 0) {
-    splits = 768 / tiles;
+    splits = target_blocks / tiles;
     const int max_splits = cdiv(p.M, 256);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
   }
   p.m_chunk = cdiv(cdiv(p.M, splits), BMK) * BMK;
   splits = cdiv(p.M, p.m_chunk);
-  hipLaunchKernelGGL((gemm_tn_kernel<BP, BQ, WP, WQ>), dim3(tiles, splits), dim3(256), 0, stream, p);
+  return tiles * splits;
+}
+
+template <int BP, int BQ, int WP, int WQ>
+int launch_tn(TnParams& p, hipStream_t stream) {
+  const int blocks = plan_tn(p, BP, BQ, 768);
+  const int tiles = p.tiles_p * p.tiles_q;
+  hipLaunchKernelGGL((gemm_tn_kernel<BP, BQ, WP, WQ>), dim3(tiles, blocks / tiles), dim3(256), 0, stream, p);
   OVLA_CHECK_LAUNCH("ovla_gemm_tn_bf16");
+  return OVLA_OK;
+}
+
+int fill_params(const ovla_gemm_tn_args* a, TnParams& p, const char* who) {
+  if (!(a && a->X && a->Y && a->C)) { ovla_set_error("%s: null pointer", who); return OVLA_EINVAL; }
+  if (!(a->M > 0 && a->P > 0 && a->Q > 0)) { ovla_set_error("%s: empty problem M=%d P=%d Q=%d", who, a->M, a->P, a->Q); return OVLA_EINVAL; }
+  if ((a->P % 8) || (a->Q % 8) || (a->ldx % 8) || (a->ldy % 8)) { ovla_set_error("%s: P, Q, ldx, ldy must be multiples of 8", who); return OVLA_EINVAL; }
+  if (!aligned16(a->X) || !aligned16(a->Y)) { ovla_set_error("%s: X/Y need 16-byte alignment", who); return OVLA_EINVAL; }
+  if (a->ldx < a->P || a->ldy < a->Q || a->ldc < a->Q) { ovla_set_error("%s: leading dimension smaller than extent", who); return OVLA_EINVAL; }
+  if (a->out_mode < 0 || a->out_mode > 2) { ovla_set_error("%s: out_mode %d", who, a->out_mode); return OVLA_EINVAL; }
+  p.X = (const bf16_bits*)a->X; p.Y = (const bf16_bits*)a->Y; p.C = a->C;
+  p.ldx = a->ldx; p.ldy = a->ldy; p.ldc = a->ldc; p.M = a->M; p.P = a->P; p.Q = a->Q; p.alpha = a->alpha; p.out_mode = a->out_mode;
   return OVLA_OK;
 }
 
@@ -158,16 +205,28 @@ int launch_tn(TnParams& p, hipStream_t stream) {
 
 extern "C" int ovla_gemm_tn_bf16(const ovla_gemm_tn_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  OVLA_REQUIRE(a && a->X && a->Y && a->C, "ovla_gemm_tn_bf16: null pointer");
-  OVLA_REQUIRE(a->M > 0 && a->P > 0 && a->Q > 0, "ovla_gemm_tn_bf16: empty problem M=%d P=%d Q=%d", a->M, a->P, a->Q);
-  OVLA_REQUIRE((a->P % 8) == 0 && (a->Q % 8) == 0 && (a->ldx % 8) == 0 && (a->ldy % 8) == 0, "ovla_gemm_tn_bf16: P, Q, ldx, ldy must be multiples of 8");
-  OVLA_REQUIRE(aligned16(a->X) && aligned16(a->Y), "ovla_gemm_tn_bf16: X/Y need 16-byte alignment");
-  OVLA_REQUIRE(a->ldx >= a->P && a->ldy >= a->Q && a->ldc >= a->Q, "ovla_gemm_tn_bf16: leading dimension smaller than extent");
-  OVLA_REQUIRE(a->out_mode >= 0 && a->out_mode <= 2, "ovla_gemm_tn_bf16: out_mode %d", a->out_mode);
   TnParams p;
-  p.X = (const bf16_bits*)a->X; p.Y = (const bf16_bits*)a->Y; p.C = a->C;
-  p.ldx = a->ldx; p.ldy = a->ldy; p.ldc = a->ldc; p.M = a->M; p.P = a->P; p.Q = a->Q; p.alpha = a->alpha; p.out_mode = a->out_mode;
+  if (int rc = fill_params(a, p, "ovla_gemm_tn_bf16")) return rc;
   if (a->P <= 32) return launch_tn<32, 128, 1, 4>(p, stream);
   if (a->Q <= 32) return launch_tn<128, 32, 4, 1>(p, stream);
   return launch_tn<128, 128, 2, 2>(p, stream);
+}
+
+extern "C" int ovla_gemm_tn_grouped(const ovla_gemm_tn_args* problems, int32_t n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(problems && n >= 1 && n <= OVLA_TN_MAX_GROUP, "ovla_gemm_tn_grouped: 1..%d problems", OVLA_TN_MAX_GROUP);
+  TnGroup g;
+  g.n = n;
+  int total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (int rc = fill_params(problems + i, g.prob[i], "ovla_gemm_tn_grouped")) return rc;
+    const TnParams& p = g.prob[i];
+    g.cfg[i] = p.P <= 32 ? 0 : (p.Q <= 32 ? 1 : 2);
+    const int bp = g.cfg[i] == 0 ? 32 : 128, bq = g.cfg[i] == 1 ? 32 : 128;
+    g.blocks[i] = plan_tn(g.prob[i], bp, bq, 768 / n);
+    total += g.blocks[i];
+  }
+  hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(total), dim3(256), 0, stream, g);
+  OVLA_CHECK_LAUNCH("ovla_gemm_tn_grouped");
+  return OVLA_OK;
 }

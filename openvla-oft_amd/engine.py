@@ -138,14 +138,22 @@ class LoraLinear:
             self.AT = None   # [in, G*r]   derived
             self.BT = None   # list of [r, group_n] derived
 
-    def refresh_derived(self):
+    def derived_pairs(self):
+        """(src, dst) transposes that re-derive A^T [in, G*r] and the stacked B_g^T [G*r, group_n] from the trainable factors."""
         if not self.has_lora:
-            return
-        self.AT = ops.transpose(self.A.data, self.AT)
-        if self.BT is None:
-            self.BT = [None] * self.groups
+            return []
+        dev = self.W.device
+        if self.AT is None:
+            self.AT = torch.empty((self.in_f, self.groups * self.r), dtype=BF16, device=dev)
+            self.BT = torch.empty((self.groups * self.r, self.group_n), dtype=BF16, device=dev)
+        pairs = [(self.A.data, self.AT)]
         for g in range(self.groups):
-            self.BT[g] = ops.transpose(self.B.data[g * self.group_n:(g + 1) * self.group_n], self.BT[g])
+            pairs.append((self.B.data[g * self.group_n:(g + 1) * self.group_n], self.BT[g * self.r:(g + 1) * self.r]))
+        return pairs
+
+    def refresh_derived(self):
+        for src, dst in self.derived_pairs():
+            ops.transpose(src, dst)
 
     def export(self, kind: str = "data") -> Dict[str, torch.Tensor]:
         """Trainable tensors (kind='data') or their fp32 gradients (kind='grad') under the reference/peft-style names."""
@@ -173,12 +181,13 @@ class LoraLinear:
         x, t_s = saved
         dx = None
         if self.has_lora:
-            M, r, G, gn = dy.shape[0], self.r, self.groups, self.group_n
-            dt = torch.empty((M, G * r), dtype=BF16, device=dy.device)
-            for g in range(G):
-                ops.gemm(dy[:, g * gn:(g + 1) * gn], self.BT[g], out=dt[:, g * r:(g + 1) * r], alpha=self.scale)
-                ops.gemm_tn(dy[:, g * gn:(g + 1) * gn], t_s[:, g * r:(g + 1) * r], out=self.B.grad[g * gn:(g + 1) * gn])
-            ops.gemm_tn(dt, x, out=self.A.grad)
+            r, G, gn = self.r, self.groups, self.group_n
+            # dt[:, g] = s * dy_g . B_g for every fused group in ONE block-diagonal skinny GEMM
+            dt = ops.gemm(dy, self.BT, alpha=self.scale, a_group_n=r if G > 1 else 0)
+            # dB_g += dy_g^T t_g ; dA += dt^T x : one grouped launch
+            probs = [(dy[:, g * gn:(g + 1) * gn], t_s[:, g * r:(g + 1) * r], self.B.grad[g * gn:(g + 1) * gn]) for g in range(G)]
+            probs.append((dt, x, self.A.grad))
+            ops.gemm_tn_grouped(probs)
             if need_dx:
                 dx = ops.gemm(dy, self.WT, a2=dt, b2=self.AT)
         elif need_dx:
@@ -601,9 +610,17 @@ class VLAEngine:
         yield from self.llm.linears()
 
     def refresh_derived(self):
-        """Re-derives A^T / B^T / bf16 compute copies from the trainable tensors (after every optimizer step)."""
-        for lin in self.all_linears():
-            lin.refresh_derived()
+        """Re-derives A^T / B^T / bf16 compute copies from the trainable tensors (after every optimizer step): all LoRA
+        transposes of the VLM go in ONE batched launch (their addresses never change, so the descriptor table is built once)."""
+        if getattr(self, "_ttab", None) is None:
+            pairs = [pr for lin in self.vlm_linears() for pr in lin.derived_pairs()]
+            self._ttab = ops.transpose_table(pairs, self.device) if pairs else False
+        if self._ttab:
+            ops.transpose_batched(self._ttab)
+        for m in (self.proprio, self.noisy, self.head):
+            if m is not None:
+                for lin in m.linears():
+                    lin.refresh_derived()
 
     def export_trainable(self, kind: str = "data") -> Dict[str, torch.Tensor]:
         """Every trainable tensor (or its fp32 gradient) keyed by the reference's parameter names: LoRA adapters as

@@ -65,11 +65,14 @@ def check_device(index: int = 0) -> None:
 
 # ----------------------------------------------------------------------------------------------------------------------
 def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=None, c_pre=None, a2=None, b2=None,
-         k2_group_n=0, film=None, split_k=1, tile=0, alpha=1.0):
+         k2_group_n=0, film=None, split_k=1, tile=0, alpha=1.0, a_group_n=0):
     """out[M,N] = epilogue(a[M,K] @ b[N,K]^T (+ a2[M,G*K2] @ b2[N,K2]^T)); all bf16 2-D, last dim contiguous."""
     _chk(a, name="a"); _chk(b, name="b")
     M, K = a.shape
     N = b.shape[0]
+    if a_group_n:   # block-diagonal: a is [M, G*K], b is [G*a_group_n, K]
+        K = b.shape[1]
+        assert a.shape[1] == (N // a_group_n) * K, f"gemm(block-diagonal): {a.shape} vs {b.shape}"
     assert b.shape[1] == K, f"gemm: K mismatch {a.shape} x {b.shape}"
     assert a.stride(1) == 1 and b.stride(1) == 1
     if out is None:
@@ -98,7 +101,7 @@ def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=Non
         gamma, beta, rows = film
         assert gamma.shape[-1] == N and gamma.is_contiguous() and beta.is_contiguous()
         g.film_gamma, g.film_beta, g.film_rows = gamma.data_ptr(), beta.data_ptr(), rows
-    g.M, g.N, g.K, g.act, g.split_k, g.tile, g.alpha = M, N, K, act, split_k, tile, alpha
+    g.M, g.N, g.K, g.act, g.split_k, g.tile, g.alpha, g.a_group_n = M, N, K, act, split_k, tile, alpha, a_group_n
     ws = _workspace(a.device, max(4 * split_k * M * N if split_k > 1 else 0, _WS_BYTES))
     g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     e0 = _prof_begin()
@@ -128,6 +131,50 @@ def gemm_tn(x, y, *, out=None, alpha=1.0, accumulate=True, out_dtype=torch.float
     _lib.call("ovla_gemm_tn_bf16", g, _stream())
     _prof_end(e0, "gemm_tn", 2.0 * M * P * Q)
     return out
+
+
+def gemm_tn_grouped(problems):
+    """problems: list of (x, y, out_fp32) with out accumulated (+=).  One launch for up to 4 TN GEMMs."""
+    import ctypes
+
+    n = len(problems)
+    arr = (STRUCTS["ovla_gemm_tn_args"] * n)()
+    flops = 0.0
+    for i, (x, y, out) in enumerate(problems):
+        _chk(x, name="x"); _chk(y, name="y")
+        M, P = x.shape
+        Q = y.shape[1]
+        assert y.shape[0] == M and x.stride(1) == 1 and y.stride(1) == 1 and out.shape == (P, Q) and out.dtype == torch.float32
+        g = arr[i]
+        g.X, g.ldx, g.Y, g.ldy, g.C, g.ldc = x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), out.data_ptr(), out.stride(0)
+        g.M, g.P, g.Q, g.alpha, g.out_mode = M, P, Q, 1.0, 0
+        flops += 2.0 * M * P * Q
+    e0 = _prof_begin()
+    _lib.check(_lib.lib().ovla_gemm_tn_grouped(arr, n, _stream()), "ovla_gemm_tn_grouped")
+    _prof_end(e0, "gemm_tn", flops)
+
+
+def transpose_table(pairs, device):
+    """Builds the device descriptor table for transpose_batched from [(src, dst)] (2-D bf16 tensors that never move)."""
+    import ctypes
+
+    T = STRUCTS["ovla_transpose_args"]
+    arr = (T * len(pairs))()
+    max_r = max_c = 0
+    for i, (src, dst) in enumerate(pairs):
+        rows, cols = src.shape
+        assert dst.shape == (cols, rows) and src.stride(1) == 1 and dst.stride(1) == 1
+        arr[i].src, arr[i].dst, arr[i].rows, arr[i].cols, arr[i].lds, arr[i].ldd = src.data_ptr(), dst.data_ptr(), rows, cols, src.stride(0), dst.stride(0)
+        max_r, max_c = max(max_r, rows), max(max_c, cols)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    return dict(table=raw, n=len(pairs), max_rows=max_r, max_cols=max_c, keep=pairs)
+
+
+def transpose_batched(tab):
+    import ctypes
+
+    ptr = ctypes.cast(ctypes.c_void_p(tab["table"].data_ptr()), ctypes.POINTER(STRUCTS["ovla_transpose_args"]))
+    _lib.check(_lib.lib().ovla_transpose_batched(ptr, tab["n"], tab["max_rows"], tab["max_cols"], _stream()), "ovla_transpose_batched")
 
 
 def colsum(x, out):

@@ -182,6 +182,31 @@ def test_gemm_tn_strided(ops, dev):
     close(out, dy[:, 128:256].float().T @ t[:, 32:64].float(), tol=2e-3, mean_tol=2e-4, what="gemm_tn strided")
 
 
+def test_gemm_tn_grouped_and_block_diagonal(ops, dev):
+    """The LoRA backward of a fused q|k|v linear: one block-diagonal skinny GEMM for dt and one grouped TN launch."""
+    torch.manual_seed(21)
+    M, G, gn, r, inn = 1000, 3, 256, 32, 384
+    dy, BT = rnd(M, G * gn, dev=dev), rnd(G * r, gn, dev=dev, scale=0.2)
+    dt = ops.gemm(dy, BT, alpha=0.5, a_group_n=r)
+    ref = torch.cat([0.5 * dy[:, g * gn:(g + 1) * gn].float() @ BT[g * r:(g + 1) * r].float().T for g in range(G)], 1)
+    close(dt, ref.to(BF), what="block-diagonal dt")
+    t, x = rnd(M, G * r, dev=dev), rnd(M, inn, dev=dev)
+    gB = torch.ones((G * gn, r), dtype=torch.float32, device=dev)
+    gA = torch.ones((G * r, inn), dtype=torch.float32, device=dev)
+    probs = [(dy[:, g * gn:(g + 1) * gn], t[:, g * r:(g + 1) * r], gB[g * gn:(g + 1) * gn]) for g in range(G)] + [(dt, x, gA)]
+    ops.gemm_tn_grouped(probs)
+    for g in range(G):
+        close(gB[g * gn:(g + 1) * gn] - 1, dy[:, g * gn:(g + 1) * gn].float().T @ t[:, g * r:(g + 1) * r].float(), tol=2e-3, mean_tol=2e-4, what=f"grouped dB{g}")
+    close(gA - 1, dt.float().T @ x.float(), tol=2e-3, mean_tol=2e-4, what="grouped dA")
+    # batched transposes
+    srcs = [rnd(96, 300, dev=dev), rnd(520, 32, dev=dev), rnd(64, 64, dev=dev)]
+    dsts = [torch.zeros((s_.shape[1], s_.shape[0]), dtype=BF, device=dev) for s_ in srcs]
+    tab = ops.transpose_table(list(zip(srcs, dsts)), dev)
+    ops.transpose_batched(tab)
+    for s_, d_ in zip(srcs, dsts):
+        assert torch.equal(d_, s_.T.contiguous())
+
+
 def test_colsum(ops, dev):
     x = rnd(1000, 264, dev=dev)
     out = torch.zeros(264, dtype=torch.float32, device=dev)
