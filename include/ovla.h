@@ -297,8 +297,9 @@ int ovla_cvt_bf16_to_f32(const void* src, float* dst, int64_t n, float scale, vo
 typedef struct { const void* src; void* dst; int32_t rows, cols; int64_t lds, ldd; } ovla_transpose_args;
 int ovla_transpose_bf16(const ovla_transpose_args* a, void* stream);
 /* Many transposes in one launch: `table` is a DEVICE array of n ovla_transpose_args (built once: the LoRA factors and
- * their derived A^T / B^T copies never move), max_rows / max_cols bound the largest entry. */
-int ovla_transpose_batched(const ovla_transpose_args* table, int32_t n, int32_t max_rows, int32_t max_cols, void* stream);
+ * their derived A^T / B^T copies never move); `tile_start` is a DEVICE int32 array of n+1 exclusive prefix sums of the
+ * entries' 64x64 tile counts, total_tiles = tile_start[n]. */
+int ovla_transpose_batched(const ovla_transpose_args* table, const int32_t* tile_start, int32_t n, int32_t total_tiles, void* stream);
 
 /* self-test hook used by tests/: dumps the MFMA / transposed-LDS-read / LDS-DMA lane layouts the kernels rely on.
  * out: fp32 [4, 64, 16] device;  src: bf16 [512] device holding 0..511. */

@@ -437,12 +437,21 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_bits* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void transpose_batched_kernel(const ovla_transpose_args* __restrict__ table, int tiles_x) {
+// One block per 64x64 tile of ANY entry: `tile_start[i]` (exclusive prefix sum of the entries' tile counts, n+1 values,
+// stored right after the descriptor table) locates the entry by binary search.
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const ovla_transpose_args* __restrict__ table, const int* __restrict__ tile_start,
+                                                                int n) {
   __shared__ bf16_bits tile[64][66];
-  const ovla_transpose_args d = table[blockIdx.y];
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int r0 = ty * 64, c0 = tx * 64;
-  if (r0 >= d.rows || c0 >= d.cols) return;
+  const int b = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tile_start[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const ovla_transpose_args d = table[lo];
+  const int t = b - tile_start[lo];
+  const int tiles_x = (d.cols + 63) / 64;
+  const int r0 = (t / tiles_x) * 64, c0 = (t % tiles_x) * 64;
   const bf16_bits* src = (const bf16_bits*)d.src;
   bf16_bits* dst = (bf16_bits*)d.dst;
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
@@ -656,11 +665,10 @@ extern "C" int ovla_transpose_bf16(const ovla_transpose_args* a, void* stream_) 
   OVLA_CHECK_LAUNCH("ovla_transpose_bf16");
   return OVLA_OK;
 }
-extern "C" int ovla_transpose_batched(const ovla_transpose_args* table, int32_t n, int32_t max_rows, int32_t max_cols, void* stream_) {
+extern "C" int ovla_transpose_batched(const ovla_transpose_args* table, const int32_t* tile_start, int32_t n, int32_t total_tiles, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  OVLA_REQUIRE(table && n > 0 && max_rows > 0 && max_cols > 0, "ovla_transpose_batched: bad arguments");
-  const int tx = cdiv(max_cols, 64), ty = cdiv(max_rows, 64);
-  hipLaunchKernelGGL(transpose_batched_kernel, dim3(tx * ty, n), dim3(256), 0, stream, table, tx);
+  OVLA_REQUIRE(table && tile_start && n > 0 && total_tiles > 0, "ovla_transpose_batched: bad arguments");
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, stream, table, tile_start, n);
   OVLA_CHECK_LAUNCH("ovla_transpose_batched");
   return OVLA_OK;
 }

@@ -36,6 +36,8 @@ struct GemmParams {
   float alpha;
   float* ws;
   int tiles_m, tiles_n, T1, T2;
+  int fast_addr;  // 1: every staged byte offset fits in 32 bits (host-checked)
+  int dbg;  // timing ablations (tools/gemm_ablate.py): bit0 = stage only the first two K tiles, bit1 = read fragments once
   int full_tiles, rem_tiles, rem_splits;  // hybrid schedule: tiles >= full_tiles are split rem_splits ways along K
 };
 
@@ -55,6 +57,33 @@ OVLA_DEV void stage_tile(const bf16_bits* __restrict__ G, int64_t ld, int row0, 
     gr = gr < row_last ? gr : row_last;
     const bf16_bits* src = (kk < K) ? (G + (int64_t)gr * ld + kk) : g_ovla_zero_chunk;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds_tile + rbase * BK), 16, 0, 0);
+  }
+}
+
+// Loop-invariant part of the staging addresses: per-lane 32-bit BYTE offsets (row clamp and chunk swizzle baked in).
+// Inside the K loop a stage is then `uniform base + k0` (scalar) plus these offsets: no vector address math per tile.
+template <int ROWS, int NW>
+OVLA_DEV void stage_offsets(uint32_t (&off)[ROWS / 8 / NW], int64_t ld, int row0, int row_last, int wave, int lane) {
+  constexpr int PER_WAVE = ROWS / 8 / NW;
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int r = (wave * PER_WAVE + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int gr = row0 + r;
+    gr = gr < row_last ? gr : row_last;
+    off[i] = (uint32_t)(((int64_t)gr * ld + c * 8) * 2);
+  }
+}
+
+template <int ROWS, int NW>
+OVLA_DEV void stage_tile_fast(const char* __restrict__ base_k /* uniform: matrix base + 2*k0 */, const uint32_t (&off)[ROWS / 8 / NW],
+                              bf16_bits* lds_tile, int wave) {
+  constexpr int PER_WAVE = ROWS / 8 / NW;
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int rbase = (wave * PER_WAVE + i) * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_k + off[i]),
                                      (__attribute__((address_space(3))) void*)(lds_tile + rbase * BK), 16, 0, 0);
   }
 }
@@ -120,7 +149,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_bits* smem = reinterpret_cast<bf16_bits*>(smem_raw);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
   // ---- block -> work unit ------------------------------------------------------------------------------------
@@ -169,10 +199,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  uint32_t offA[BM / 8 / NW], offB[BN / 8 / NW];
+  stage_offsets<BM, NW>(offA, p.lda, m0, p.M - 1, wave, lane);
+  stage_offsets<BN, NW>(offB, p.ldb, n0, p.N - 1, wave, lane);
+  const int t_fast = p.fast_addr ? p.K / BK : 0;   // K tiles that lie entirely inside [0, K): no zero-chunk select needed
+
   auto stage = [&](int t, int buf) {
     bf16_bits* sA = smem + buf * TILE_ELEMS;
     bf16_bits* sB = sA + BM * BK;
-    if (t < p.T1) {
+    if (t < t_fast) {
+      stage_tile_fast<BM, NW>(reinterpret_cast<const char*>(Ablk) + (int64_t)t * (BK * 2), offA, sA, wave);
+      stage_tile_fast<BN, NW>(reinterpret_cast<const char*>(p.B) + (int64_t)t * (BK * 2), offB, sB, wave);
+    } else if (t < p.T1) {
       const int k0 = t * BK;
       stage_tile<BM, NW>(Ablk, p.lda, m0, p.M - 1, k0, p.K, sA, wave, lane);
       stage_tile<BN, NW>(p.B, p.ldb, n0, p.N - 1, k0, p.K, sB, wave, lane);
@@ -188,8 +226,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     const int buf = (t - t_begin) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA for tile t has landed
     __syncthreads();                                   // ... everyone's has; and buf^1 is no longer being read
-    if (t + 1 < t_end) stage(t + 1, buf ^ 1);
-    const bf16_bits* sA = smem + buf * TILE_ELEMS;
+    if (t + 1 < t_end && !((p.dbg & 1) && t > t_begin)) stage(t + 1, buf ^ 1);
+    const bf16_bits* sA = smem + ((p.dbg & 2) ? 0 : buf) * TILE_ELEMS;
     const bf16_bits* sB = sA + BM * BK;
     // MFMA rows r = (k-substep s, m-tile i).  Fragment reads run one row ahead of the MFMAs: while row r's NT MFMAs
     // issue, the A fragment of row r+1 and a slice of the NEXT substep's B fragments are in flight, so the two waves
@@ -300,6 +338,30 @@ OVLA_DEV void stage_tile32(const bf16_bits* __restrict__ G, int64_t ld, int row0
   }
 }
 
+template <int ROWS, int NW>
+OVLA_DEV void stage_offsets32(uint32_t (&off)[ROWS / 16 / NW], int64_t ld, int row0, int row_last, int wave, int lane) {
+  constexpr int PER_WAVE = ROWS / 16 / NW;
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int r = (wave * PER_WAVE + i) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((4 - ((r >> 2) & 3)) & 3);
+    int gr = row0 + r;
+    gr = gr < row_last ? gr : row_last;
+    off[i] = (uint32_t)(((int64_t)gr * ld + c * 8) * 2);
+  }
+}
+
+template <int ROWS, int NW>
+OVLA_DEV void stage_tile32_fast(const char* __restrict__ base_k, const uint32_t (&off)[ROWS / 16 / NW], bf16_bits* lds_tile, int wave) {
+  constexpr int PER_WAVE = ROWS / 16 / NW;
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int rbase = (wave * PER_WAVE + i) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_k + off[i]),
+                                     (__attribute__((address_space(3))) void*)(lds_tile + rbase * PK), 16, 0, 0);
+  }
+}
+
 OVLA_DEV bf16x8_bits lds_frag32(const bf16_bits* tile, int row, int chunk) {
   const int phys = chunk ^ ((4 - ((row >> 2) & 3)) & 3);
   return *reinterpret_cast<const bf16x8_bits*>(tile + row * PK + phys * 8);
@@ -368,10 +430,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_pipe_kernel(const GemmPa
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  uint32_t offA[BM / 16 / NW], offB[BN / 16 / NW];
+  stage_offsets32<BM, NW>(offA, p.lda, m0, p.M - 1, wave, lane);
+  stage_offsets32<BN, NW>(offB, p.ldb, n0, p.N - 1, wave, lane);
+  const int t_fast = p.fast_addr ? p.K / PK : 0;
+
   auto stage = [&](int t) {
     bf16_bits* sA = smem + ((t - t_begin) % STAGES) * STAGE_ELEMS;
     bf16_bits* sB = sA + BM * PK;
-    if (t < T1) {
+    if (t < t_fast) {
+      stage_tile32_fast<BM, NW>(reinterpret_cast<const char*>(p.A) + (int64_t)t * (PK * 2), offA, sA, wave);
+      stage_tile32_fast<BN, NW>(reinterpret_cast<const char*>(p.B) + (int64_t)t * (PK * 2), offB, sB, wave);
+    } else if (t < T1) {
       const int k0 = t * PK;
       stage_tile32<BM, NW>(p.A, p.lda, m0, p.M - 1, k0, p.K, sA, wave, lane);
       stage_tile32<BN, NW>(p.B, p.ldb, n0, p.N - 1, k0, p.K, sB, wave, lane);
@@ -650,8 +720,10 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   p.T1 = cdiv(p.K, BK); p.T2 = p.K2 > 0 ? cdiv(p.K2, BK) : 0;
   if (p.split_k > p.T1 + p.T2) p.split_k = p.T1 + p.T2;
   p.full_tiles = 0; p.rem_tiles = 0; p.rem_splits = 1;
+  p.dbg = (a->tile >= 1000) ? (a->tile / 1000) : 0;
+  p.fast_addr = ((int64_t)p.M * p.lda * 2 < (int64_t)4e9 && (int64_t)p.N * p.ldb * 2 < (int64_t)4e9) ? 1 : 0;
 
-  int tile = a->tile;
+  int tile = a->tile % 1000;
   const int64_t wsb = a->workspace ? a->workspace_bytes : 0;
   bool hybrid = false;
   if (tile == 0) {

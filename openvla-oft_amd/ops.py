@@ -160,21 +160,22 @@ def transpose_table(pairs, device):
 
     T = STRUCTS["ovla_transpose_args"]
     arr = (T * len(pairs))()
-    max_r = max_c = 0
+    starts = [0]
     for i, (src, dst) in enumerate(pairs):
         rows, cols = src.shape
         assert dst.shape == (cols, rows) and src.stride(1) == 1 and dst.stride(1) == 1
         arr[i].src, arr[i].dst, arr[i].rows, arr[i].cols, arr[i].lds, arr[i].ldd = src.data_ptr(), dst.data_ptr(), rows, cols, src.stride(0), dst.stride(0)
-        max_r, max_c = max(max_r, rows), max(max_c, cols)
+        starts.append(starts[-1] + ((rows + 63) // 64) * ((cols + 63) // 64))
     raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
-    return dict(table=raw, n=len(pairs), max_rows=max_r, max_cols=max_c, keep=pairs)
+    tile_start = torch.tensor(starts, dtype=torch.int32).to(device)
+    return dict(table=raw, tile_start=tile_start, n=len(pairs), total=starts[-1], keep=pairs)
 
 
 def transpose_batched(tab):
     import ctypes
 
     ptr = ctypes.cast(ctypes.c_void_p(tab["table"].data_ptr()), ctypes.POINTER(STRUCTS["ovla_transpose_args"]))
-    _lib.check(_lib.lib().ovla_transpose_batched(ptr, tab["n"], tab["max_rows"], tab["max_cols"], _stream()), "ovla_transpose_batched")
+    _lib.check(_lib.lib().ovla_transpose_batched(ptr, tab["tile_start"].data_ptr(), tab["n"], tab["total"], _stream()), "ovla_transpose_batched")
 
 
 def colsum(x, out):
