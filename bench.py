@@ -111,6 +111,81 @@ def cpu_baseline(cfg, S, train_flops_per_sample):
                       f"{reps} reps of {dt:.2f} s = {rate / 1e12:.3f} TFLOP/s, scaled by FLOPs to the full {train_flops_per_sample / 1e12:.1f} TFLOP/sample step"}
 
 
+def eager_baseline(cfg, batch_size, steps, warmup, dev):
+    """the same step executed by stock PyTorch-ROCm eager ops (hipBLASLt GEMMs, SDPA, unfused LoRA as
+    separate matmuls, torch.optim.AdamW, autograd), bf16 weights and activations, including the lm_head + fp32 logits +
+    cross-entropy that the reference computes and discards in L1 mode (finetune.py:338-351).  Runs the oracle's module
+    code in its "native" mode on the GPU: a timing baseline, not a parity reference."""
+    from oracle import vla_oracle as vo
+    load = importlib.import_module
+    weights_mod, synth = load("openvla-oft_amd.weights"), load("openvla-oft_amd.synthetic")
+    sd = weights_mod.random_state_dict(cfg, dev, seed=0, lm_head=True)
+    # the towers' last block exists in the reference and runs although its output is discarded
+    for prefix, vc in (("vision_backbone.featurizer.", cfg.dino), ("vision_backbone.fused_featurizer.", cfg.siglip)):
+        src = f"{prefix}blocks.{vc.depth - 2}."
+        for k in [k for k in sd if k.startswith(src)]:
+            sd[k.replace(src, f"{prefix}blocks.{vc.depth - 1}.")] = sd[k].clone()
+    trainable = [k for k in sd if ".lora_" in k or k.startswith(("action_head.", "proprio_projector."))]
+    for k in trainable:
+        sd[k].requires_grad_(True)
+    ocfg = vo.OracleConfig(**{f: getattr(cfg, f) for f in ("llm_dim", "llm_layers", "llm_heads", "llm_ff", "vocab", "rms_eps", "rope_theta",
+                                                          "num_images", "lora_rank", "lora_alpha", "action_dim", "chunk", "proprio_dim")},
+                           dino=vo.VitConfig(**{f: getattr(cfg.dino, f) for f in ("dim", "depth", "heads", "mlp_hidden", "n_prefix", "layerscale", "patch", "image_size")}),
+                           siglip=vo.VitConfig(**{f: getattr(cfg.siglip, f) for f in ("dim", "depth", "heads", "mlp_hidden", "n_prefix", "layerscale", "patch", "image_size")}))
+
+    class FullDepth(vo.Oracle):   # run ALL ViT blocks like timm does (the oracle skips the discarded one)
+        def vit(self, img, prefix, vc, film_avg=None):
+            out = super().vit(img, prefix, vc, film_avg)
+            B, H, hd = img.shape[0], vc.heads, vc.dim // vc.heads
+            p = f"{prefix}blocks.{vc.depth - 1}."
+            x = torch.cat([out.new_zeros(B, vc.n_prefix, vc.dim), out], 1)
+            h = torch.nn.functional.layer_norm(x, (vc.dim,), self.W(p + "norm1.weight"), self.W(p + "norm1.bias"), vc.eps)
+            qkv = self.linear(h, p + "attn.qkv").reshape(B, -1, 3, H, hd).permute(2, 0, 3, 1, 4)
+            a = torch.nn.functional.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, -1, vc.dim)
+            x = x + self.linear(a, p + "attn.proj")
+            h = torch.nn.functional.layer_norm(x, (vc.dim,), self.W(p + "norm2.weight"), self.W(p + "norm2.bias"), vc.eps)
+            self._dead = x + self.linear(self.act(self.linear(h, p + "mlp.fc1")), p + "mlp.fc2")
+            return out
+
+    o = FullDepth(ocfg, sd, mode="native")
+    opt = torch.optim.AdamW([sd[k] for k in trainable], lr=5e-4)
+    batch = synth.make_batch(batch_size, seed=1000)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    for k in ("pixel_values", "actions", "proprio"):
+        batch[k] = batch[k].to(torch.bfloat16)
+
+    def step():
+        loss, _, _ = o.train_forward(batch)
+        # the discarded language-modelling loss of PrismaticForConditionalGeneration.forward(labels=...) (modeling_prismatic.py:632-643)
+        hidden, P = o._last_hidden
+        logits = (hidden @ sd["language_model.lm_head.weight"].T).float()
+        labels = torch.cat([batch["labels"][:, :1], torch.full((batch_size, P), -100, device=dev), batch["labels"][:, 1:]], 1)
+        torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), labels[:, 1:].reshape(-1), ignore_index=-100)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    orig = o.multimodal_hidden
+
+    def keep(*a, **k):
+        r = orig(*a, **k)
+        o._last_hidden = (r[0].detach(), r[1])
+        return r
+
+    o.multimodal_hidden = keep
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"kind": "torch-eager (stock PyTorch-ROCm ops, bf16, hipBLASLt + SDPA + torch.optim.AdamW)", "ms_per_step": 1e3 * dt,
+            "samples_per_s": batch_size / dt, "loss": loss.item(), "peak_mem_gib": torch.cuda.max_memory_allocated() / 2**30}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,18 +194,25 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (reference recipe: 8, LIBERO.md:91-113)")
     ap.add_argument("--tiny", action="store_true", help="reduced-size model (plumbing check only; NOT a valid benchmark number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager-baseline", action="store_true", help="time the stock PyTorch-ROCm eager step instead (BASELINE.md B1) and exit")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("OVLA_DIST_BACKEND", "nccl")   # "gloo": rehearsal of the multi-process path on a 1-GPU box
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
 
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     pkg = importlib.import_module("openvla-oft_amd")
     load = importlib.import_module
@@ -143,6 +225,11 @@ def main():
                                    siglip=config_mod.VitConfig(144, 3, 2, 536))
     else:
         cfg = config_mod.OPENVLA_7B
+    if args.eager_baseline:
+        res = eager_baseline(cfg, args.batch, args.steps, args.warmup, dev)
+        print(json.dumps({"metric": "fine-tune samples/s (action-chunks/s) OpenVLA-7B bf16 [torch eager baseline]", "value": res["samples_per_s"],
+                          "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, **res}))
+        return
     t_init = time.time()
     sd = weights_mod.random_state_dict(cfg, dev, seed=0, lm_head=False)   # identical on every rank (DDP broadcast equivalent)
     get, has = weights_mod.make_getter(sd, dev)
@@ -158,6 +245,7 @@ def main():
     batch["proprio"] = batch["proprio"].to(dev, torch.bfloat16)
     S = 1 + cfg.num_images * cfg.dino.n_patches + 1 + (batch["input_ids"].shape[1] - 1)
     reducer = dp_mod.GradReducer(eng.stores, world) if world > 1 else None
+    eng.attach_reducer(reducer)
     if rank == 0:
         print(f"[bench] init {time.time() - t_init:.1f}s, trainable params {eng.num_trainable() / 1e6:.1f} M, S={S}, "
               f"HBM allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB", file=sys.stderr)
@@ -185,7 +273,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     ms_per_step = 1e3 * elapsed / args.steps
@@ -193,11 +281,13 @@ def main():
     final_loss = loss_sum.item() / (args.batch * cfg.chunk * cfg.action_dim)
 
     roofline = cpu = None
+    # dominant kernel (gemm_nt) timed launch by launch with HIP events on the launch stream over one more step.  EVERY rank
+    # runs the step (it contains the gradient collectives); only rank 0 records events.
     if rank == 0:
-        # dominant kernel (gemm_nt) timed launch by launch with HIP events on the launch stream over one more step
         ops.PROFILE = []
-        step()
-        torch.cuda.synchronize()
+    step()
+    torch.cuda.synchronize()
+    if rank == 0:
         fam = {}
         for family, e0, e1, fl in ops.PROFILE:
             d = fam.setdefault(family, [0, 0.0, 0.0])

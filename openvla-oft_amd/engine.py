@@ -362,6 +362,7 @@ class LlamaStack:
         self.norm_w = get("language_model.model.norm.weight")
         self.hd = D // cfg.llm_heads
         self.cos = self.sin = None
+        self.on_grads_ready = None
 
     def linears(self):
         for l in self.layers:
@@ -403,7 +404,7 @@ class LlamaStack:
         D, H, hd, F = cfg.llm_dim, cfg.llm_heads, self.hd, cfg.llm_ff
         causal = cfg.mask_mode == "causal"
         dx = ops.norm_bwd(x_last, dout, self.norm_w, None, rf, rms=True)
-        for l, sv in zip(reversed(self.layers), reversed(saved)):
+        for li, (l, sv) in enumerate(zip(reversed(self.layers), reversed(saved))):
             x, r1, s_qkv, qkv, o, lse, s_o, x2, r2, s_gu, gu, s_d = sv
             dh = l["down"].bwd(dx, s_d)
             dgu = ops.swiglu_bwd(gu, dh)
@@ -416,6 +417,8 @@ class LlamaStack:
             ops.rope_(dqkv, S, 2 * H, hd, self.cos, self.sin, inverse=True)
             dh1 = l["qkv"].bwd(dqkv, s_qkv)
             ops.norm_bwd(x, dh1, l["n1"], None, r1, rms=True, dx=dx, dx_accum=True)                    # dx = d x
+            if self.on_grads_ready is not None:   # this layer's LoRA gradients are final: the reducer may ship them
+                self.on_grads_ready(l["qkv"].A)
         return dx
 
 
@@ -585,6 +588,8 @@ class VLAEngine:
     def zero_grad(self):
         for st in self.stores:
             st.zero_grad()
+        if getattr(self, "reducer", None) is not None:
+            self.reducer.reset()
 
     def adamw_step(self, lr: float, **kw):
         for st in self.stores:
@@ -672,7 +677,8 @@ class VLAEngine:
         d = self.proj[2].bwd(dpatches, s3)
         d = self.proj[1].bwd(ops.act_bwd(z2, d, ops.ACT_GELU), s2)
         dfeat = self.proj[0].bwd(ops.act_bwd(z1, d, ops.ACT_GELU), s1)            # [B*I*Np, vd]
-        for k, (tower, col0) in enumerate(((self.dino, 0), (self.siglip, cfg.dino.dim))):
+        # SigLIP first: its parameters precede DINOv2's in the backward-ordered flat gradient buffer
+        for k, (tower, col0) in reversed(list(enumerate(((self.dino, 0), (self.siglip, cfg.dino.dim))))):
             vc = tower.vc
             T = vc.n_patches + vc.n_prefix
             dtok = torch.zeros((B * I * T, vc.dim), dtype=BF16, device=self.device)
@@ -748,6 +754,21 @@ class VLAEngine:
         dpatches = dmm[:, 1: 1 + n_vis].contiguous().view(B * n_vis, D)
         self.vision_bwd(dpatches, vsaved)
 
+    def attach_reducer(self, reducer, overlap: bool = True):
+        """Overlaps the data-parallel gradient all-reduce with the backward: the head's gradients go out as soon as its
+        backward is done, each Llama layer's LoRA gradients as soon as that layer is done (the flat buffers are in
+        completion order), the rest (projector, ViT towers, proprio projector) at the end of the step."""
+        self.reducer = reducer
+        self._overlap = overlap and reducer is not None
+        if not self._overlap:
+            self.llm.on_grads_ready = None
+            return
+
+        def llm_layer_done(first_param):   # first-registered param of the layer = LAST in the reversed layout
+            reducer.notify(self.store, BF16, first_param.offset + (first_param.numel + ParamStore.ALIGN - 1) // ParamStore.ALIGN * ParamStore.ALIGN)
+
+        self.llm.on_grads_ready = llm_layer_done
+
     def train_step_fwd_bwd(self, batch: dict, loss_scale: float = 1.0, action_head=None, proprio_projector=None):
         """One run_forward_pass (finetune.py:280-451, L1 branch) + backward.  Gradients accumulate in the flat buffers.
         Returns (loss_sum fp32[1] device, element count, predictions)."""
@@ -762,6 +783,9 @@ class VLAEngine:
         pred, loss_sum, hsaved = head.fwd(ah, target=target, mse=False, train=True)
         # ---- backward ----
         dah = head.bwd(hsaved, dloss=loss_scale)
+        if getattr(self, "_overlap", False) and hasattr(head, "store"):
+            for dt, g in head.store.flat_grad.items():
+                self.reducer.notify(head.store, dt, g.numel())
         dhidden = torch.zeros((B * S, D), dtype=BF16, device=self.device)
         ops.gather_rows(dah, idx, D, dst=dhidden, scatter_add=True)
         self.backward_from_hidden(dhidden, out["saved"])

@@ -184,6 +184,7 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
     engine = VLAEngine(model_config, get, dev, lora=True, use_proprio=cfg.use_proprio, head="l1", has=has)
     log(f"# total trainable params: {engine.num_trainable()}")
     reducer = GradReducer(engine.stores, world) if world > 1 else None
+    engine.attach_reducer(reducer, overlap=cfg.grad_accumulation_steps == 1)   # overlap only when every backward ends a step
     if dataset is None:
         def synthetic_stream():
             step = 0

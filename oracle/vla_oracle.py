@@ -264,8 +264,11 @@ class Oracle:
     FiLM as <vit>.blocks.{i}.scale.* / .shift.*)."""
 
     def __init__(self, cfg: OracleConfig, sd: Dict[str, torch.Tensor], mode: str = "fp32", mask_mode: str = "bidirectional"):
-        assert mode in ("fp32", "bf16") and mask_mode in ("bidirectional", "causal")
+        # mode "native": tensors stay in the dtype/device they are given in (bf16 on a GPU) and every op is the stock
+        # PyTorch op -- the reference's eager execution path, used by bench.py --eager-baseline as the timing baseline
+        assert mode in ("fp32", "bf16", "native") and mask_mode in ("bidirectional", "causal")
         self.cfg, self.sd, self.mode, self.mask_mode = cfg, sd, mode, mask_mode
+        self.dev = next(iter(sd.values())).device
 
     # -- rounding points of the bf16-autocast reference ---------------------------------------------------------------
     def R(self, x):
@@ -273,6 +276,8 @@ class Oracle:
 
     def W(self, name):
         w = self.sd[name]
+        if self.mode == "native":
+            return w
         return w.to(torch.float32) if not w.requires_grad else w.float()
 
     def linear(self, x, name: str):
@@ -355,12 +360,19 @@ class Oracle:
 
     # -- Llama (transformers LlamaModel; call site modeling_prismatic.py:632-643) --------------------------------------
     def rope(self, S: int, hd: int):
-        inv_freq = 1.0 / (self.cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
-        freqs = torch.arange(S, dtype=torch.float32)[:, None] * inv_freq[None, :]
+        inv_freq = 1.0 / (self.cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32, device=self.dev) / hd))
+        freqs = torch.arange(S, dtype=torch.float32, device=self.dev)[:, None] * inv_freq[None, :]
         emb = torch.cat((freqs, freqs), dim=-1)
+        if self.mode == "native":
+            dt = self.sd["language_model.model.norm.weight"].dtype
+            return emb.cos().to(dt), emb.sin().to(dt)
         return self.R(emb.cos()), self.R(emb.sin())
 
     def rmsnorm(self, x, name):
+        if self.mode == "native":   # transformers LlamaRMSNorm: fp32 statistics, cast back, then scale
+            xf = x.float()
+            xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + self.cfg.rms_eps)
+            return self.W(name) * xf.to(x.dtype)
         v = x.pow(2).mean(-1, keepdim=True)
         return self.R(self.W(name) * self.R(x * torch.rsqrt(v + self.cfg.rms_eps)))
 
@@ -371,11 +383,11 @@ class Oracle:
         B, S, D = embeds.shape
         H, hd = self.cfg.llm_heads, D // self.cfg.llm_heads
         cos, sin = self.rope(S, hd)
-        bias = torch.zeros((B, 1, S, S), dtype=torch.float32)
+        bias = torch.zeros((B, 1, S, S), dtype=embeds.dtype, device=self.dev)
         if attention_mask is not None:
             bias = bias.masked_fill(~attention_mask.bool()[:, None, None, :], float("-inf"))
         if self.mask_mode == "causal":
-            bias = bias.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1)[None, None], float("-inf"))
+            bias = bias.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool, device=self.dev), 1)[None, None], float("-inf"))
 
         def rot(x):
             return torch.cat((-x[..., hd // 2:], x[..., : hd // 2]), dim=-1)
@@ -438,7 +450,7 @@ class Oracle:
             film_avg = self.R(lang.mean(dim=1))                                         # film_vit_wrapper.py:243
         patches = self.projector(self.vision_backbone(pixel_values, film_avg))          # :586
         if proprio is not None:                                                         # :589-591, :449-459
-            pf = self.mlp_projector(self.R(proprio.reshape(patches.shape[0], -1).float()), "proprio_projector.")
+            pf = self.mlp_projector(self.R(proprio.reshape(patches.shape[0], -1).to(patches.dtype)), "proprio_projector.")
             patches = torch.cat((patches, pf[:, None, :]), dim=1)
         if timestep_emb is not None:                                                    # :594-599
             patches = torch.cat((patches, self.R(timestep_emb)), dim=1)
@@ -453,7 +465,7 @@ class Oracle:
         mm = torch.cat([emb[:, :1], patches, emb[:, 1:]], dim=1)                        # :474-476
         mm_mask = None
         if attention_mask is not None:
-            ones = torch.ones((patches.shape[0], patches.shape[1]), dtype=torch.bool)
+            ones = torch.ones((patches.shape[0], patches.shape[1]), dtype=torch.bool, device=self.dev)
             mm_mask = torch.cat([attention_mask[:, :1].bool(), ones, attention_mask[:, 1:].bool()], dim=1)
         return self.llm(mm, mm_mask), patches.shape[1]
 
@@ -462,12 +474,13 @@ class Oracle:
         """vla-scripts/finetune.py:280-451 run_forward_pass (L1-regression or diffusion branch).  Returns
         (loss, predicted actions or noise, actions_hidden_states)."""
         cfg = self.cfg
-        gt = self.R(batch["actions"].float())                                           # :324 (.to(bfloat16))
+        gt = batch["actions"] if self.mode == "native" else self.R(batch["actions"].float())   # :324 (.to(bfloat16))
         noisy, temb = None, None
         if use_diffusion:                                                               # action_heads.py:167-197
             noisy = self.R(ddim.add_noise(gt, noise, timesteps))
             temb = self.R(sinusoidal_encoding(timesteps.float(), cfg.llm_dim))[:, None, :]
-        hidden, P = self.multimodal_hidden(batch["input_ids"], batch["attention_mask"], self.R(batch["pixel_values"].float()),
+        pv = batch["pixel_values"] if self.mode == "native" else self.R(batch["pixel_values"].float())
+        hidden, P = self.multimodal_hidden(batch["input_ids"], batch["attention_mask"], pv,
                                            batch["labels"], batch["proprio"] if use_proprio else None, noisy, temb, use_film)
         gt_ids = batch["labels"][:, 1:]                                                 # :353
         m = current_action_mask(gt_ids, cfg.action_dim) | next_actions_mask(gt_ids, cfg.action_dim)

@@ -34,7 +34,14 @@ def _worker(rank, world, port, out):
     stores = [_Store(rank), _Store(rank + 10)]
     red = dp.GradReducer(stores, world, bucket_bytes=1024)      # force several buckets per buffer
     assert len(list(red.buckets())) > 8
+    # overlapped protocol: frontiers arrive during the "backward", the tail goes out in all_reduce(); every element must
+    # be reduced exactly once
+    red.notify(stores[0], torch.bfloat16, 300)
+    red.notify(stores[0], torch.bfloat16, 700)
+    red.notify(stores[0], torch.bfloat16, 650)     # a stale frontier is a no-op
+    red.notify(stores[1], torch.float32, 333)
     red.all_reduce()
+    red.all_reduce()                               # second call in the same step: nothing left to ship
     torch.save([{str(k): v for k, v in s.flat_grad.items()} for s in stores], f"{out}/rank{rank}.pt")
     dist.destroy_process_group()
 
