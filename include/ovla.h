@@ -65,7 +65,7 @@ typedef struct {
   const void* A2; int64_t lda2;  /* optional K-extension (LoRA) */
   const void* B2; int64_t ldb2;
   void* C; int64_t ldc;          /* bf16 [M,N] */
-  void* C_pre;                   /* optional bf16 [M,N] (ldc): value before the activation (saved for backward) */
+  void* C_pre;                   /* optional bf16 [M,N] (ldc): value before the activation; with FiLM: before the modulation */
   const void* bias;              /* optional bf16 [N] */
   const void* colscale;          /* optional bf16 [N]  (timm LayerScale) */
   const void* residual; int64_t ldr; /* optional bf16 [M,N] */
@@ -219,7 +219,13 @@ typedef struct {
 } ovla_copy_rows_args;
 int ovla_copy_rows(const ovla_copy_rows_args* a, void* stream);
 
-/* FiLM modulation backward helpers / mean pooling:  out[b,:] = mean_{i<len[b] valid rows} x[b, i, :]  */
+/* FiLM backward (prismatic/models/film_vit_wrapper.py:72: x = x_pre * (1 + gamma[b]) + beta[b], b = row / rows_per_batch):
+ *   dgamma[b,n] += sum_rows dy * x_pre ;  dbeta[b,n] += sum_rows dy ;  dy <- dy * (1 + gamma[b,n])   (in place)
+ * dgamma / dbeta fp32 [B, dim] (accumulated), gamma bf16 [B, dim]. */
+typedef struct { void* dy; const void* x_pre; const void* gamma; float* dgamma; float* dbeta; int32_t B, rows_per_batch, dim; } ovla_film_bwd_args;
+int ovla_film_bwd(const ovla_film_bwd_args* a, void* stream);
+
+/* mean pooling:  out[b,:] = mean over rows i with row_mask[b,i] != 0 of x[b, i, :]  (FiLM's average language embedding) */
 typedef struct { const void* x; const uint8_t* row_mask; void* out; int32_t B, L, dim; } ovla_masked_mean_args;
 int ovla_masked_mean(const ovla_masked_mean_args* a, void* stream);
 

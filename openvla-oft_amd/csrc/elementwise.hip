@@ -342,6 +342,26 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(const bf16_bits* __res
   out[(int64_t)b * dim + col] = f2bf(s / (float)(cnt > 0 ? cnt : 1));
 }
 
+// FiLM backward: one thread per (batch, column), walking the batch's rows (coalesced across the 256 columns of a block).
+__global__ __launch_bounds__(256) void film_bwd_kernel(bf16_bits* __restrict__ dy, const bf16_bits* __restrict__ x_pre,
+                                                       const bf16_bits* __restrict__ gamma, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, int rows, int dim, int row_chunk) {
+  const int b = blockIdx.y, col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= dim) return;
+  const int r0 = blockIdx.z * row_chunk, r1 = (r0 + row_chunk) < rows ? (r0 + row_chunk) : rows;
+  const float one_plus = bfround(1.0f + bf2f(gamma[(int64_t)b * dim + col]));
+  float sg = 0.f, sb = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const int64_t idx = ((int64_t)b * rows + r) * dim + col;
+    const float d = bf2f(dy[idx]);
+    sg += d * bf2f(x_pre[idx]);
+    sb += d;
+    dy[idx] = f2bf(d * one_plus);
+  }
+  atomicAdd(dgamma + (int64_t)b * dim + col, sg);
+  atomicAdd(dbeta + (int64_t)b * dim + col, sb);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Multimodal assembly.  One workgroup per output row (b, s).  The action mask follows train_utils.py:8-39 exactly:
 // cumsum(labels != IGNORE) >= 1 and labels > ACTION_TOKEN_BEGIN_IDX.
@@ -613,6 +633,15 @@ extern "C" int ovla_copy_rows(const ovla_copy_rows_args* a, void* stream_) {
                      a->rows, a->dim, a->src_batch_stride, a->src_row0, a->src_ld, a->dst_batch_stride, a->dst_row0, a->dst_ld,
                      a->dst_col0, a->accumulate);
   OVLA_CHECK_LAUNCH("ovla_copy_rows");
+  return OVLA_OK;
+}
+extern "C" int ovla_film_bwd(const ovla_film_bwd_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->dy && a->x_pre && a->gamma && a->dgamma && a->dbeta && a->B > 0 && a->rows_per_batch > 0 && a->dim > 0, "ovla_film_bwd: bad arguments");
+  const int chunk = 32;
+  hipLaunchKernelGGL(film_bwd_kernel, dim3(cdiv(a->dim, 256), a->B, cdiv(a->rows_per_batch, chunk)), dim3(256), 0, stream, (bf16_bits*)a->dy,
+                     (const bf16_bits*)a->x_pre, (const bf16_bits*)a->gamma, a->dgamma, a->dbeta, a->rows_per_batch, a->dim, chunk);
+  OVLA_CHECK_LAUNCH("ovla_film_bwd");
   return OVLA_OK;
 }
 extern "C" int ovla_masked_mean(const ovla_masked_mean_args* a, void* stream_) {

@@ -104,7 +104,7 @@ OVLA_DEV void epilogue_store(const GemmParams& p, int m, int n, f32x4 v) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = bfround(v[j]);
   }
-  if (p.Cpre) {
+  if (p.Cpre && !p.film_gamma) {   // value before the activation (saved for the backward)
     bf16x4_bits o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(v[j]);
@@ -125,6 +125,12 @@ OVLA_DEV void epilogue_store(const GemmParams& p, int m, int n, f32x4 v) {
     for (int j = 0; j < 4; ++j) v[j] = bfround(v[j] + bf2f((bf16_bits)r[j]));
   }
   if (p.film_gamma) {
+    if (p.Cpre) {   // with FiLM, C_pre receives the value BEFORE the modulation (needed for d gamma)
+      bf16x4_bits o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(v[j]);
+      *reinterpret_cast<bf16x4_bits*>(p.Cpre + (int64_t)m * p.ldc + n) = o;
+    }
     const int64_t off = (int64_t)(m / p.film_rows) * p.N + n;
     const bf16x4_bits g = *reinterpret_cast<const bf16x4_bits*>(p.film_gamma + off);
     const bf16x4_bits b = *reinterpret_cast<const bf16x4_bits*>(p.film_beta + off);

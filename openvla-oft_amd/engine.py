@@ -213,6 +213,9 @@ class FullLinear:
         self.b = store.add(name + ".bias", bias.to(dt)) if bias is not None else None
         self.Wc = self.bc = None
 
+    def derived_pairs(self):
+        return []   # nothing to transpose; the bf16 compute copy is refreshed by refresh_derived()
+
     def refresh_derived(self):
         if self.master_fp32:
             self.Wc = ops.cvt_f32_to_bf16(self.W.data, self.Wc)
@@ -276,9 +279,14 @@ class VitTower:
 
         # only blocks 0 .. depth-2 are ever used: the forward returns the output of block depth-2
         # (get_intermediate_layers(n={depth-2})); the last block's output is discarded (film_vit_wrapper.py:124-137)
+        self.film = film
         for i in range(vc.depth - 1):
             p = f"{prefix}blocks.{i}."
-            blk = dict(ln1_w=get(p + "norm1.weight"), ln1_b=get(p + "norm1.bias"), ln2_w=get(p + "norm2.weight"), ln2_b=get(p + "norm2.bias"),
+            fl = None
+            if film:   # film_vit_wrapper.py:53-54: fp32 nn.Linear(llm_dim, vision_dim) pairs, trained in full
+                fl = (FullLinear(store, p + "scale", get(p + "scale.weight").float(), get(p + "scale.bias").float(), master_fp32=True),
+                      FullLinear(store, p + "shift", get(p + "shift.weight").float(), get(p + "shift.bias").float(), master_fp32=True))
+            blk = dict(film=fl, ln1_w=get(p + "norm1.weight"), ln1_b=get(p + "norm1.bias"), ln2_w=get(p + "norm2.weight"), ln2_b=get(p + "norm2.bias"),
                        qkv=L(p + "attn.qkv"), proj=L(p + "attn.proj"), fc1=L(p + "mlp.fc1"), fc2=L(p + "mlp.fc2"),
                        ls1=get(p + "ls1.scale_factor") if vc.layerscale else None, ls2=get(p + "ls2.scale_factor") if vc.layerscale else None)
             self.blocks.append(blk)
@@ -286,8 +294,10 @@ class VitTower:
     def linears(self):
         for b in self.blocks:
             yield from (b["qkv"], b["proj"], b["fc1"], b["fc2"])
+            if b["film"] is not None:
+                yield from b["film"]
 
-    def fwd(self, pixels, c0: int, n_img: int, train: bool):
+    def fwd(self, pixels, c0: int, n_img: int, train: bool, film_avg=None):
         """pixels bf16 [B, 6*n_img, H, W]; image i uses channels [c0 + 6 i, +3).  All images go through the tower as one
         batch of B*n_img (ordered (b, img)).  Returns (tokens [B*n_img*T, dim] after block depth-2, saved)."""
         vc = self.vc
@@ -302,13 +312,23 @@ class VitTower:
             h1, mean1, rstd1 = ops.norm_fwd(x, blk["ln1_w"], blk["ln1_b"], eps=vc.eps, rms=False, save_stats=train)
             qkv, s_qkv = blk["qkv"].fwd(h1)
             o, lse = ops.attn_fwd(qkv[:, : vc.dim], qkv[:, vc.dim: 2 * vc.dim], qkv[:, 2 * vc.dim:], B, T, H, hd)
-            x2, s_proj = blk["proj"].fwd(o, residual=x, colscale=blk["ls1"])
+            fsv = None
+            if blk["film"] is not None:
+                # x = (x + ls1 * attn(...)) * (1 + gamma) + beta, gamma/beta = Linear(mean language embedding) per SAMPLE
+                # (both images of a sample share them): fused into the proj GEMM's epilogue
+                gamma, s_sc = blk["film"][0].fwd(film_avg)
+                beta, s_sh = blk["film"][1].fwd(film_avg)
+                xpre = torch.empty_like(x) if train else None
+                x2, s_proj = blk["proj"].fwd(o, residual=x, colscale=blk["ls1"], film=(gamma, beta, n_img * T), c_pre=xpre)
+                fsv = (gamma, s_sc, s_sh, xpre, n_img * T)
+            else:
+                x2, s_proj = blk["proj"].fwd(o, residual=x, colscale=blk["ls1"])
             h2, mean2, rstd2 = ops.norm_fwd(x2, blk["ln2_w"], blk["ln2_b"], eps=vc.eps, rms=False, save_stats=train)
             z = torch.empty((h2.shape[0], vc.mlp_hidden), dtype=BF16, device=h2.device) if train else None
             hmid, s_fc1 = blk["fc1"].fwd(h2, act=self.act, c_pre=z)
             x3, s_fc2 = blk["fc2"].fwd(hmid, residual=x2, colscale=blk["ls2"])
             if train:
-                saved.append((x, mean1, rstd1, s_qkv, qkv, o, lse, s_proj, x2, mean2, rstd2, s_fc1, z, s_fc2))
+                saved.append((x, mean1, rstd1, s_qkv, qkv, o, lse, s_proj, x2, mean2, rstd2, s_fc1, z, s_fc2, fsv))
             x = x3
         return x, (saved, B)
 
@@ -319,13 +339,21 @@ class VitTower:
         T = vc.n_patches + vc.n_prefix
         H, hd = vc.heads, vc.head_dim
         for blk, sv in zip(reversed(self.blocks), reversed(saved)):
-            x, mean1, rstd1, s_qkv, qkv, o, lse, s_proj, x2, mean2, rstd2, s_fc1, z, s_fc2 = sv
+            x, mean1, rstd1, s_qkv, qkv, o, lse, s_proj, x2, mean2, rstd2, s_fc1, z, s_fc2, fsv = sv
             # x3 = x2 + ls2 * fc2(act(fc1(ln2(x2))))
             d = ops.colscale(dx, blk["ls2"]) if blk["ls2"] is not None else dx
             dh = blk["fc2"].bwd(d, s_fc2)
             dz = ops.act_bwd(z, dh, self.act)
             dh2 = blk["fc1"].bwd(dz, s_fc1)
             ops.norm_bwd(x2, dh2, blk["ln2_w"], mean2, rstd2, rms=False, dx=dx, dx_accum=True)       # dx now = d x2
+            if fsv is not None:   # through the FiLM modulation: dgamma, dbeta, dx <- dx * (1 + gamma)
+                gamma, s_sc, s_sh, xpre, frows = fsv
+                nb = gamma.shape[0]
+                dg = torch.zeros((nb, vc.dim), dtype=F32, device=dx.device)
+                db = torch.zeros((nb, vc.dim), dtype=F32, device=dx.device)
+                ops.film_bwd(dx, xpre, gamma, dg, db, dx.shape[0] // frows, frows)
+                blk["film"][0].bwd(ops.cvt_f32_to_bf16(dg), s_sc, need_dx=False)
+                blk["film"][1].bwd(ops.cvt_f32_to_bf16(db), s_sh, need_dx=False)
             # x2 = x + ls1 * proj(attn(qkv(ln1(x))))
             d = ops.colscale(dx, blk["ls1"]) if blk["ls1"] is not None else dx
             do = blk["proj"].bwd(d, s_proj)
@@ -458,6 +486,12 @@ class ActionHead:
         cfg = self.cfg
         rows = actions_hidden.shape[0] // cfg.action_dim
         x0 = actions_hidden.view(rows, cfg.action_dim * cfg.llm_dim)
+        rows_real = rows
+        if rows % 8:   # e.g. ALOHA: batch 4 x chunk 25; the GEMM-shaped data gradients want M % 8 == 0: zero-pad the rows
+            rows = (rows + 7) // 8 * 8
+            xp = torch.zeros((rows, x0.shape[1]), dtype=BF16, device=x0.device)
+            xp[:rows_real] = x0
+            x0 = xp
         h0, m0, r0 = ops.norm_fwd(x0, self.ln1_w.data, self.ln1_b.data, eps=1e-5, rms=False, save_stats=train)
         z1 = torch.empty((rows, cfg.llm_dim), dtype=BF16, device=x0.device) if train else None
         split = 8 if rows <= 256 else 1      # small-M weight stream: split K over the chip
@@ -472,8 +506,8 @@ class ActionHead:
             x = xn
         h2, m2, r2 = ops.norm_fwd(x, self.ln2_w.data, self.ln2_b.data, eps=1e-5, rms=False, save_stats=train)
         loss_sum = torch.zeros(1, dtype=F32, device=x0.device) if target is not None else None
-        pred = ops.head_out_fwd(h2, self.out_w.data, self.out_b.data, target, loss_sum, mse=mse)
-        saved = (x0, m0, r0, z1, s1, blocks_saved, x, m2, r2, h2, pred, target, mse) if train else None
+        pred = ops.head_out_fwd(h2[:rows_real], self.out_w.data, self.out_b.data, target, loss_sum, mse=mse)
+        saved = (x0, m0, r0, z1, s1, blocks_saved, x, m2, r2, h2, pred, target, mse, rows_real) if train else None
         return pred, loss_sum, saved
 
     def bwd(self, saved, dloss: float = 1.0, dpred=None):
@@ -481,10 +515,14 @@ class ActionHead:
         [rows, action_dim]) the upstream gradient is taken as given (loss computed by the caller); otherwise the fused
         L1 / MSE gradient of mean-reduced loss * dloss is used."""
         cfg = self.cfg
-        x0, m0, r0, z1, s1, blocks_saved, xl, m2, r2, h2, pred, target, mse = saved
+        x0, m0, r0, z1, s1, blocks_saved, xl, m2, r2, h2, pred, target, mse, rows_real = saved
         rows = x0.shape[0]
-        dh2 = ops.head_out_bwd(h2, self.out_w.data, pred, target, dloss / (rows * cfg.action_dim), self.out_w.grad, self.out_b.grad, mse=mse,
-                               dpred=dpred)
+        dh2 = ops.head_out_bwd(h2[:rows_real], self.out_w.data, pred, target, dloss / (rows_real * cfg.action_dim), self.out_w.grad, self.out_b.grad,
+                               mse=mse, dpred=dpred)
+        if rows != rows_real:
+            dp = torch.zeros((rows, h2.shape[1]), dtype=BF16, device=h2.device)
+            dp[:rows_real] = dh2
+            dh2 = dp
         dx = ops.norm_bwd(xl, dh2, self.ln2_w.data, m2, r2, rms=False, dweight=self.ln2_w.grad, dbias=self.ln2_b.grad)
         for b, (xin, mb, rb, zb, sb) in zip(reversed(self.blocks), reversed(blocks_saved)):
             dz = ops.act_bwd(zb, dx, ops.ACT_RELU)
@@ -493,7 +531,7 @@ class ActionHead:
         dz1 = ops.act_bwd(z1, dx, ops.ACT_RELU)
         dh0 = self.fc1.bwd(dz1, s1)
         dx0 = ops.norm_bwd(x0, dh0, self.ln1_w.data, m0, r0, rms=False, dweight=self.ln1_w.grad, dbias=self.ln1_b.grad)
-        return dx0.view(rows * cfg.action_dim, cfg.llm_dim)
+        return dx0[:rows_real].reshape(rows_real * cfg.action_dim, cfg.llm_dim)
 
 
 class MlpProjector:
@@ -546,16 +584,15 @@ class VLAEngine:
 
     def __init__(self, cfg: VLAConfig, get, device, *, lora: bool = True, use_proprio: bool = True, head: str = "l1", use_film: bool = False,
                  has=None):
-        if use_film:
-            raise NotImplementedError("FiLM (config 5) is a later SURVEY section 8 row; not built yet")
         if head not in ("l1", "diffusion", "none"):
             raise ValueError(head)
         ops.check_device(device.index or 0)
         self.cfg, self.device, self.lora = cfg, device, lora
         st = self.store = ParamStore(device)
         # registration order = forward order (the store reverses it into backward order)
-        self.dino = VitTower(st, "vision_backbone.featurizer.", cfg.dino, get, cfg, lora)
-        self.siglip = VitTower(st, "vision_backbone.fused_featurizer.", cfg.siglip, get, cfg, lora)
+        self.use_film = use_film
+        self.dino = VitTower(st, "vision_backbone.featurizer.", cfg.dino, get, cfg, lora, film=use_film)
+        self.siglip = VitTower(st, "vision_backbone.fused_featurizer.", cfg.siglip, get, cfg, lora, film=use_film)
         s = cfg.lora_scale
 
         def L(name):
@@ -622,6 +659,9 @@ class VLAEngine:
             self._ttab = ops.transpose_table(pairs, self.device) if pairs else False
         if self._ttab:
             ops.transpose_batched(self._ttab)
+        for lin in self.vlm_linears():
+            if isinstance(lin, FullLinear):   # FiLM scale / shift: refresh the bf16 compute copies of the fp32 masters
+                lin.refresh_derived()
         for m in (self.proprio, self.noisy, self.head):
             if m is not None:
                 for lin in m.linears():
@@ -644,7 +684,7 @@ class VLAEngine:
         return self.cfg.dino.n_patches * num_images + int(use_proprio) + int(use_diffusion)
 
     # -- forward pieces ----------------------------------------------------------------------------------------------------
-    def vision_fwd(self, pixel_values, train: bool):
+    def vision_fwd(self, pixel_values, train: bool, film_avg=None):
         """pixel_values bf16 [B, 6*I, H, W] -> projected patches bf16 [B, I*Np, D] rows, saved.
         modeling_prismatic.py:186-227 + :250-262."""
         cfg = self.cfg
@@ -656,7 +696,7 @@ class VLAEngine:
         for tower, c0, col0 in ((self.dino, 0, 0), (self.siglip, 3, cfg.dino.dim)):
             vc = tower.vc
             T = vc.n_patches + vc.n_prefix
-            tok, sv = tower.fwd(pixel_values, c0, I, train)
+            tok, sv = tower.fwd(pixel_values, c0, I, train, film_avg)
             # drop prefix tokens, concat features on dim 2 and images on dim 1 (modeling_prismatic.py:221-227)
             ops.copy_rows(tok, feats, B * I, Np, vc.dim, src_batch_stride=T * vc.dim, src_row0=vc.n_prefix, src_ld=vc.dim,
                           dst_batch_stride=Np * vd, dst_row0=0, dst_ld=vd, dst_col0=col0)
@@ -688,10 +728,26 @@ class VLAEngine:
             tower.bwd(dtok, tower_saved[k])
 
     # -- the training step pieces -------------------------------------------------------------------------------------------
+    def language_average(self, ids_dev, labels_cpu):
+        """FiLM conditioning vector: mean of the token embeddings at every NON-action position of the text (BOS, prompt,
+        stop AND pad tokens: modeling_prismatic.py:581-583 averages `input_embeddings[~all_actions_mask]`;
+        film_vit_wrapper.py:243).  Returned padded to a multiple of 8 rows (GEMM M granularity of the FiLM Linears)."""
+        cfg = self.cfg
+        B, L = ids_dev.shape
+        cum = torch.cumsum(labels_cpu != -100, dim=1)
+        amask = (labels_cpu > 31743) & (cum >= 1)                        # train_utils.py:8-39 (host-side integer logic)
+        keep = (~amask).to(torch.uint8).to(self.device).contiguous()
+        emb = ops.gather_rows(self.embed, ids_dev.reshape(-1).to(torch.int32).contiguous(), cfg.llm_dim)
+        avg = torch.zeros(((B + 7) // 8 * 8, cfg.llm_dim), dtype=BF16, device=self.device)
+        avg[:B] = ops.masked_mean(emb, keep, B, L, cfg.llm_dim)
+        return avg
+
     def forward(self, input_ids, attention_mask, pixel_values, labels, proprio=None, noisy_actions=None, timestep_emb=None, train=False,
-                proprio_projector=None, noisy_action_projector=None):
+                proprio_projector=None, noisy_action_projector=None, cached_patches=None):
         """Multimodal forward (modeling_prismatic.py:571-643 without the discarded lm_head/CE in L1/diffusion mode).
-        Returns dict(hidden [B,S,D], P, action_rows [B,A], saved)."""
+        Returns dict(hidden [B,S,D], P, action_rows [B,A], patches, saved).  `cached_patches` (the `patches` of a previous
+        call) skips the vision towers / projector / proprio projector: the DDIM sampler reuses them across its steps
+        (modeling_prismatic.py:810)."""
         cfg = self.cfg
         dev = self.device
         B, L = input_ids.shape
@@ -701,38 +757,43 @@ class VLAEngine:
         lens = am.sum(1)
         if not bool((am == (torch.arange(L)[None, :] < lens[:, None])).all()):
             raise ValueError("attention_mask must be right padding (a prefix of ones per row), as produced by the reference collator")
-        patches, vsaved = self.vision_fwd(pixel_values.to(dev, BF16).contiguous(), train)
         proprio_projector = proprio_projector if proprio_projector is not None else self.proprio
         noisy_action_projector = noisy_action_projector if noisy_action_projector is not None else self.noisy
-        extra, psaved, nsaved = [], None, None
-        if proprio is not None and proprio_projector is not None:
-            pr = torch.zeros(((B + 7) // 8 * 8, cfg.proprio_dim), dtype=BF16, device=dev)
-            pr[:B] = proprio.reshape(B, -1).to(dev, BF16)
-            pf, psaved = proprio_projector.fwd(pr, train)
-            extra.append(pf[:B].reshape(B, 1, cfg.llm_dim))
-        if timestep_emb is not None:
-            extra.append(timestep_emb.to(dev, BF16).reshape(B, 1, cfg.llm_dim))
-        if extra:
-            # token concat along the sequence dim (pure data movement)
-            allp = torch.empty((B, patches.shape[1] + len(extra), cfg.llm_dim), dtype=BF16, device=dev)
-            allp[:, : patches.shape[1]] = patches
-            for j, e in enumerate(extra):
-                allp[:, patches.shape[1] + j] = e[:, 0]
+        vsaved = psaved = nsaved = None
+        if cached_patches is not None:
+            base, n_vis = cached_patches
         else:
-            allp = patches
+            film_avg = self.language_average(ids, labels.to("cpu")) if self.use_film else None
+            patches, vsaved = self.vision_fwd(pixel_values.to(dev, BF16).contiguous(), train, film_avg)
+            n_vis = patches.shape[1]
+            base = patches
+            if proprio is not None and proprio_projector is not None:
+                pr = torch.zeros(((B + 7) // 8 * 8, cfg.proprio_dim), dtype=BF16, device=dev)
+                pr[:B] = proprio.reshape(B, -1).to(dev, BF16)
+                pf, psaved = proprio_projector.fwd(pr, train)
+                base = torch.empty((B, n_vis + 1, cfg.llm_dim), dtype=BF16, device=dev)   # token concat (pure data movement)
+                base[:, :n_vis] = patches
+                base[:, n_vis] = pf[:B]
+        allp = base
+        if timestep_emb is not None:
+            allp = torch.empty((B, base.shape[1] + 1, cfg.llm_dim), dtype=BF16, device=dev)
+            allp[:, : base.shape[1]] = base
+            allp[:, base.shape[1]] = timestep_emb.to(dev, BF16).reshape(B, cfg.llm_dim)
         P = allp.shape[1]
         A = cfg.num_action_tokens
         noisy_feats = None
         if noisy_actions is not None:
-            na = noisy_actions.reshape(B * A, 1).to(dev, BF16)
+            rows = (B * A + 7) // 8 * 8
+            na = torch.zeros((rows, 1), dtype=BF16, device=dev)
+            na[: B * A] = noisy_actions.reshape(B * A, 1).to(dev, BF16)
             nf, nsaved = noisy_action_projector.fwd(na, train)
-            noisy_feats = nf.view(B, A, cfg.llm_dim)
+            noisy_feats = nf[: B * A].view(B, A, cfg.llm_dim)
         mm, action_rows = ops.assemble_multimodal(ids, lab, self.embed, allp.contiguous(), A=A, noisy=noisy_feats, action_dim=cfg.action_dim)
         S = P + L
         kv_len = (lens + P).to(torch.int32).to(dev)
         hidden, lsaved = self.llm.fwd(mm.view(B * S, cfg.llm_dim), B, S, kv_len, train)
-        saved = (vsaved, psaved, nsaved, lsaved, B, S, P, patches.shape[1], proprio_projector, noisy_action_projector) if train else None
-        return dict(hidden=hidden.view(B, S, cfg.llm_dim), P=P, action_rows=action_rows, saved=saved)
+        saved = (vsaved, psaved, nsaved, lsaved, B, S, P, n_vis, proprio_projector, noisy_action_projector, action_rows) if train else None
+        return dict(hidden=hidden.view(B, S, cfg.llm_dim), P=P, action_rows=action_rows, patches=(base, n_vis), saved=saved)
 
     def gather_action_hidden(self, hidden, action_rows):
         """Rows of hidden that predict the action slots: the hidden state at token i-1 predicts token i
@@ -744,9 +805,17 @@ class VLAEngine:
 
     def backward_from_hidden(self, dhidden, saved):
         """dhidden bf16 [B*S, D] (gradient of hidden_states[-1]) -> accumulates every VLM / projector gradient."""
-        vsaved, psaved, nsaved, lsaved, B, S, P, n_vis, proprio_projector, noisy_action_projector = saved
+        vsaved, psaved, nsaved, lsaved, B, S, P, n_vis, proprio_projector, noisy_action_projector, action_rows = saved
         D = self.cfg.llm_dim
-        dmm = self.llm.bwd(dhidden, lsaved).view(B, S, D)
+        dmm_flat = self.llm.bwd(dhidden, lsaved)
+        dmm = dmm_flat.view(B, S, D)
+        if nsaved is not None:
+            # the projected noisy-action features sit AT the action slots: one row after the row that predicts them
+            slot_rows = (action_rows.reshape(-1) + 1).contiguous()
+            n = slot_rows.numel()
+            dn = torch.zeros(((n + 7) // 8 * 8, D), dtype=BF16, device=self.device)
+            ops.gather_rows(dmm_flat, slot_rows, D, dst=dn)
+            noisy_action_projector.bwd(dn, nsaved)
         if psaved is not None:
             dpr = torch.zeros(((B + 7) // 8 * 8, D), dtype=BF16, device=self.device)
             dpr[:B] = dmm[:, 1 + n_vis]
@@ -769,18 +838,24 @@ class VLAEngine:
 
         self.llm.on_grads_ready = llm_layer_done
 
-    def train_step_fwd_bwd(self, batch: dict, loss_scale: float = 1.0, action_head=None, proprio_projector=None):
-        """One run_forward_pass (finetune.py:280-451, L1 branch) + backward.  Gradients accumulate in the flat buffers.
-        Returns (loss_sum fp32[1] device, element count, predictions)."""
+    def train_step_fwd_bwd(self, batch: dict, loss_scale: float = 1.0, action_head=None, proprio_projector=None, diffusion=None,
+                           noisy_action_projector=None):
+        """One run_forward_pass (finetune.py:280-451) + backward.  L1 branch by default; with
+        `diffusion = dict(noise, noisy_actions, timestep_emb)` the noise-prediction MSE branch (:402-407).
+        Gradients accumulate in the flat buffers.  Returns (loss_sum fp32[1] device, element count, predictions)."""
         cfg = self.cfg
         head = action_head if action_head is not None else self.head
+        kw = {}
+        if diffusion is not None:
+            kw = dict(noisy_actions=diffusion["noisy_actions"], timestep_emb=diffusion["timestep_emb"], noisy_action_projector=noisy_action_projector)
         out = self.forward(batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["labels"], proprio=batch.get("proprio"),
-                           train=True, proprio_projector=proprio_projector)
+                           train=True, proprio_projector=proprio_projector, **kw)
         hidden = out["hidden"]
         B, S, D = hidden.shape
         ah, idx = self.gather_action_hidden(hidden, out["action_rows"])
-        target = batch["actions"].to(self.device, BF16).reshape(B * cfg.chunk, cfg.action_dim).contiguous()
-        pred, loss_sum, hsaved = head.fwd(ah, target=target, mse=False, train=True)
+        tgt_src = diffusion["noise"] if diffusion is not None else batch["actions"]
+        target = tgt_src.to(self.device, BF16).reshape(B * cfg.chunk, cfg.action_dim).contiguous()
+        pred, loss_sum, hsaved = head.fwd(ah, target=target, mse=diffusion is not None, train=True)
         # ---- backward ----
         dah = head.bwd(hsaved, dloss=loss_scale)
         if getattr(self, "_overlap", False) and hasattr(head, "store"):

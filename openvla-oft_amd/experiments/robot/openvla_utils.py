@@ -18,7 +18,7 @@ import torch
 
 from ... import image_prep
 from ...config import OPENVLA_7B, VLAConfig
-from ...modeling import L1RegressionActionHead, NoisyActionProjector, OpenVLAForActionPrediction, ProprioProjector
+from ...modeling import DiffusionActionHead, L1RegressionActionHead, NoisyActionProjector, OpenVLAForActionPrediction, ProprioProjector
 from ...prismatic.vla import constants as C
 
 DEVICE = torch.device("cuda:0") if torch.cuda.is_available() else torch.device("cpu")
@@ -79,11 +79,12 @@ def get_noisy_action_projector(cfg: Any, llm_dim: int) -> NoisyActionProjector:
 
 def get_action_head(cfg: Any, llm_dim: int):
     assert not (cfg.use_l1_regression and cfg.use_diffusion), "Cannot use both L1 regression and diffusion action head!"
-    if cfg.use_diffusion:
-        raise NotImplementedError("DiffusionActionHead is not built yet in this port (SURVEY.md section 8, row a11)")
-    if not cfg.use_l1_regression:
+    if not (cfg.use_l1_regression or cfg.use_diffusion):
         raise ValueError("Either use_l1_regression or use_diffusion must be True")
     sd = load_component_state_dict(find_checkpoint_file(cfg.pretrained_checkpoint, "action_head"))
+    if cfg.use_diffusion:
+        return DiffusionActionHead(llm_dim, llm_dim, C.ACTION_DIM, num_diffusion_steps=cfg.num_diffusion_steps, num_actions_chunk=C.NUM_ACTIONS_CHUNK,
+                                   device=DEVICE, state_dict=sd).eval()
     return L1RegressionActionHead(llm_dim, llm_dim, C.ACTION_DIM, num_actions_chunk=C.NUM_ACTIONS_CHUNK, device=DEVICE, state_dict=sd).eval()
 
 

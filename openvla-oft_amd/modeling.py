@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from . import ops
 from .config import VLAConfig
+from .diffusion import DDIMScheduler, SinusoidalPositionalEncoding
 from .engine import ActionHead, MlpProjector, ParamStore, VLAEngine, build_component
 from .weights import make_getter
 
@@ -175,6 +176,33 @@ class L1RegressionActionHead(_StoreModule):
         self._build(sd)
 
 
+class DiffusionActionHead(L1RegressionActionHead):
+    """prismatic/models/action_heads.py:144-211: the same MLPResNet predicting the noise, plus the DDIM scheduler and the
+    sinusoidal timestep encoder."""
+
+    prefix = "noise_predictor.mlp_resnet."
+
+    def __init__(self, input_dim: int = 4096, hidden_dim: int = 4096, action_dim: int = 7, num_diffusion_steps: int = 100, **kw):
+        super().__init__(input_dim, hidden_dim, action_dim, **kw)
+        self.noise_scheduler = DDIMScheduler(num_train_timesteps=num_diffusion_steps, beta_schedule="squaredcos_cap_v2")
+        self.num_diffusion_steps = num_diffusion_steps
+        self.time_encoder = SinusoidalPositionalEncoding(dim=hidden_dim)
+
+    def sample_noisy_actions(self, ground_truth_actions: torch.Tensor, generator: Optional[torch.Generator] = None):
+        """action_heads.py:167-197 (host-side: a chunk is a few hundred numbers)."""
+        gt = ground_truth_actions.detach().to("cpu", torch.float32)
+        B = gt.shape[0]
+        noise = torch.randn(gt.shape, generator=generator).to(BF16).float()
+        timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (B,), generator=generator)
+        noisy = self.noise_scheduler.add_noise(gt, noise, timesteps).to(BF16)
+        temb = self.time_encoder(timesteps.float()).to(BF16).unsqueeze(1)
+        return dict(noise=noise.to(BF16), noisy_actions=noisy, diffusion_timestep_embeddings=temb, timesteps=timesteps)
+
+    def predict_noise(self, actions_hidden_states: torch.Tensor) -> torch.Tensor:
+        """action_heads.py:199-211"""
+        return self.predict_action(actions_hidden_states)
+
+
 class ProprioProjector(_StoreModule):
     """prismatic/models/projectors.py:6-24 (fp32 parameters, bf16 compute: finetune.py:895-901 never casts it)."""
 
@@ -257,9 +285,9 @@ class _VLMFn(torch.autograd.Function):
         B, S, D = dhidden.shape
         eng.backward_from_hidden(dhidden.to(BF16).contiguous().view(B * S, D), ctx.saved)
         ctx.vla.publish_grads()
-        pp = ctx.saved[8]
-        if pp is not None and hasattr(pp, "owner"):
-            pp.owner.publish_grads()
+        for comp in (ctx.saved[8], ctx.saved[9]):
+            if comp is not None and hasattr(comp, "owner"):
+                comp.owner.publish_grads()
         return None, None, None, None
 
 
@@ -267,13 +295,15 @@ class OpenVLAForActionPrediction(_StoreModule):
     """prismatic/extern/hf/modeling_prismatic.py:720-1087 over the HIP engine."""
 
     def __init__(self, cfg: VLAConfig, state_dict: Dict[str, torch.Tensor], *, device=None, lora: Optional[bool] = None,
-                 norm_stats: Optional[dict] = None):
+                 norm_stats: Optional[dict] = None, use_film: Optional[bool] = None):
         self.cfg = cfg
         self.device = _device(device)
         get, has = make_getter(state_dict, self.device)
         if lora is None:
             lora = any(k.endswith(".lora_A.weight") for k in state_dict)
-        self.engine = VLAEngine(cfg, get, self.device, lora=lora, use_proprio=False, head="none", has=has)
+        if use_film is None:
+            use_film = any(".scale.weight" in k for k in state_dict)
+        self.engine = VLAEngine(cfg, get, self.device, lora=lora, use_proprio=False, head="none", has=has, use_film=use_film)
         self.store = self.engine.store
         self.llm_dim = cfg.llm_dim
         self.norm_stats = norm_stats or {}
@@ -300,12 +330,13 @@ class OpenVLAForActionPrediction(_StoreModule):
             raise ValueError("Non-homogenous batch of (text, image) input -- forward() does not support mixed batches!")
         if past_key_values is not None or inputs_embeds is not None:
             raise ValueError("cached generation / inputs_embeds are not part of the parallel-decoding action path")
-        if use_film:
-            raise NotImplementedError("FiLM is not built yet in this port (SURVEY.md section 8, config 5)")
+        if use_film != self.engine.use_film:
+            raise ValueError(f"use_film={use_film} but the model was built with use_film={self.engine.use_film} (FiLM adds parameters to the "
+                             "vision backbone: finetune.py:874-888, openvla_utils.py:311-349)")
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids, dtype=torch.bool)
         self._reset_if_cleared()
-        for m in (proprio_projector,):
+        for m in (proprio_projector, noisy_action_projector):
             if m is not None:
                 m._reset_if_cleared()
                 m.comp.owner = m
@@ -337,6 +368,8 @@ class OpenVLAForActionPrediction(_StoreModule):
     def predict_action(self, input_ids=None, unnorm_key=None, proprio=None, proprio_projector=None, action_head=None,
                        noisy_action_projector=None, use_film: bool = False, **kwargs):
         cfg = self.cfg
+        if use_film != self.engine.use_film:
+            raise ValueError(f"use_film={use_film} but the model was built with use_film={self.engine.use_film}")
         A = cfg.num_action_tokens
         assert input_ids.shape[0] == 1, "Generation is only currently supported for batch size of 1!"
         pixel_values, attention_mask = kwargs["pixel_values"], kwargs["attention_mask"]
@@ -350,10 +383,28 @@ class OpenVLAForActionPrediction(_StoreModule):
         labels = torch.full_like(ids, IGNORE_INDEX)                                      # :983-993
         labels[:, input_ids.shape[-1]:] = ACTION_TOKEN_BEGIN_IDX + 1
         labels[:, -1] = STOP_INDEX
-        if noisy_action_projector is not None and hasattr(action_head, "noise_scheduler"):
-            raise NotImplementedError("diffusion sampling is not built yet in this port (SURVEY.md section 8, row a11)")
         use_proprio = proprio_projector is not None and proprio is not None
         prop = torch.as_tensor(np.asarray(proprio), dtype=torch.float32) if use_proprio else None
+        use_diffusion = noisy_action_projector is not None and hasattr(action_head, "noise_scheduler")
+        if use_diffusion:                                                                 # :793-877
+            sched = action_head.noise_scheduler
+            sched.set_timesteps(action_head.num_diffusion_steps)
+            cur = kwargs.get("noise")
+            if cur is None:
+                cur = torch.randn((1, cfg.chunk, cfg.action_dim))
+            cur = cur.to("cpu", torch.float32).to(BF16).float()
+            cached, ah = None, None
+            for t in sched.timesteps:
+                temb = action_head.time_encoder(torch.tensor([float(t)])).to(BF16)
+                out = self.engine.forward(ids, mask, pixel_values, labels, proprio=prop, train=False, noisy_actions=cur.to(BF16),
+                                          timestep_emb=temb, proprio_projector=proprio_projector.comp if use_proprio else None,
+                                          noisy_action_projector=noisy_action_projector.comp, cached_patches=cached)
+                cached = out["patches"]                                                   # vision features reused across steps (:810)
+                ah, _ = self.engine.gather_action_hidden(out["hidden"], out["action_rows"])
+                eps = action_head.predict_noise(ah.view(1, A, cfg.llm_dim)).reshape(cur.shape).float().cpu()
+                cur = sched.step(eps, int(t), cur).prev_sample.to(BF16).float()
+            normalized = cur.reshape(cfg.chunk, cfg.action_dim).numpy()
+            return self._unnormalize_actions(normalized, unnorm_key), ah.view(1, A, cfg.llm_dim)
         out = self.engine.forward(ids, mask, pixel_values, labels, proprio=prop, train=False,
                                   proprio_projector=proprio_projector.comp if use_proprio else None)
         ah, _ = self.engine.gather_action_hidden(out["hidden"], out["action_rows"])       # rows P+NPT .. P+NPT+A-1 (:915-920)

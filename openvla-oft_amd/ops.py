@@ -363,6 +363,15 @@ def copy_rows(src, dst, B, rows, dim, *, src_batch_stride, src_row0, src_ld, dst
     return dst
 
 
+def film_bwd(dy, x_pre, gamma, dgamma, dbeta, B, rows_per_batch):
+    """In place: dy <- dy * (1 + gamma[b]); accumulates dgamma / dbeta (fp32 [B, dim])."""
+    g = STRUCTS["ovla_film_bwd_args"]()
+    g.dy, g.x_pre, g.gamma, g.dgamma, g.dbeta = dy.data_ptr(), x_pre.data_ptr(), gamma.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
+    g.B, g.rows_per_batch, g.dim = B, rows_per_batch, dy.shape[1]
+    _lib.call("ovla_film_bwd", g, _stream())
+    return dy
+
+
 def masked_mean(x, row_mask, B, L, dim):
     out = torch.empty((B, dim), dtype=BF16, device=x.device)
     g = STRUCTS["ovla_masked_mean_args"]()

@@ -1,2 +1,3 @@
 """prismatic.models.action_heads (mirror of the reference module path)."""
-from ...modeling import L1RegressionActionHead  # noqa: F401
+from ...diffusion import SinusoidalPositionalEncoding  # noqa: F401
+from ...modeling import DiffusionActionHead, L1RegressionActionHead  # noqa: F401

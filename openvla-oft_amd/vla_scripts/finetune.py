@@ -112,19 +112,30 @@ def run_forward_pass(vla, action_head, noisy_action_projector, proprio_projector
                      ) -> Tuple[torch.Tensor, Dict[str, float]]:
     """finetune.py:280-451 with the reference's signature, L1-regression branch, through the autograd bridge of
     modeling.py (`loss.backward()` then drives the engine's explicit backward)."""
-    if use_diffusion or not use_l1_regression:
-        raise NotImplementedError("only the L1-regression objective is built in this port so far (SURVEY.md section 8)")
+    if not (use_l1_regression or use_diffusion):
+        raise NotImplementedError("the discrete next-token objective is not part of the OFT recipes built here")
     metrics = {}
     gt = batch["actions"].to(device_id).to(torch.bfloat16)
+    noisy = None
+    if use_diffusion:                                                                   # :327-333
+        noisy = action_head.module.sample_noisy_actions(gt)
     output = vla(input_ids=batch["input_ids"], attention_mask=batch["attention_mask"], pixel_values=batch["pixel_values"], labels=batch["labels"],
                  output_hidden_states=True, proprio=batch["proprio"] if use_proprio else None,
-                 proprio_projector=proprio_projector if use_proprio else None, use_film=use_film)
+                 proprio_projector=proprio_projector if use_proprio else None, use_film=use_film,
+                 noisy_actions=noisy["noisy_actions"] if use_diffusion else None,
+                 noisy_action_projector=noisy_action_projector if use_diffusion else None,
+                 diffusion_timestep_embeddings=noisy["diffusion_timestep_embeddings"] if use_diffusion else None)
     ids = batch["labels"][:, 1:].to(device_id)
     cur, nxt = get_current_action_mask(ids), get_next_actions_mask(ids)
     last = output.hidden_states[-1]
     text_hidden = last[:, num_patches:-1]
     B = batch["input_ids"].shape[0]
     ah = text_hidden[cur | nxt].reshape(B, C.NUM_ACTIONS_CHUNK * C.ACTION_DIM, -1).to(torch.bfloat16)
+    if use_diffusion:                                                                   # :402-407
+        noise_pred = action_head.module.predict_noise(ah).reshape(noisy["noise"].shape)
+        loss = torch.nn.functional.mse_loss(noise_pred, noisy["noise"].to(noise_pred.device), reduction="mean")
+        metrics["loss_value"] = loss.item()
+        return loss, metrics
     pred = action_head.module.predict_action(ah)
     loss = torch.nn.L1Loss()(gt, pred)
     metrics["loss_value"] = loss.item()
@@ -147,9 +158,10 @@ def save_training_checkpoint(run_dir: Path, log_step: int, engine: VLAEngine, da
         from safetensors.torch import save_file
 
         save_file({k: v.contiguous() for k, v in exp.items() if ".lora_" in k}, str(ckpt / "lora_adapter" / "adapter_model.safetensors"))
-        groups = {"proprio_projector": "proprio_projector.", "noisy_action_projector": "noisy_action_projector.", "action_head": "action_head."}
+        groups = {"proprio_projector": "proprio_projector.", "noisy_action_projector": "noisy_action_projector.", "action_head": "action_head.",
+                  "vision_backbone": "vision_backbone."}   # FiLM scale/shift Linears (finetune.py:640-645 saves the wrapped backbone)
         for comp, prefix in groups.items():
-            sd = {k[len(prefix):]: v.contiguous() for k, v in exp.items() if k.startswith(prefix)}
+            sd = {k[len(prefix):]: v.contiguous() for k, v in exp.items() if k.startswith(prefix) and ".lora_" not in k}
             if sd:
                 torch.save(sd, ckpt / f"{comp}--{suffix}")
     return ckpt
@@ -160,8 +172,8 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
     """finetune.py:763-1154.  Returns the logged metric history."""
     assert cfg.use_lora, "Only LoRA fine-tuning is supported. Please set --use_lora=True!"
     assert not (cfg.use_l1_regression and cfg.use_diffusion), "Cannot do both L1 regression and diffusion. Please pick one of them!"
-    if cfg.use_diffusion or cfg.use_film or not cfg.use_l1_regression:
-        raise NotImplementedError("this port builds the L1-regression recipe (LIBERO.md:91-115); diffusion / FiLM are later SURVEY section 8 rows")
+    if not (cfg.use_l1_regression or cfg.use_diffusion):
+        raise NotImplementedError("the discrete next-token objective (no continuous head) is not part of the OFT recipes built here")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -179,9 +191,15 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
                                 "proprio_dim": C.PROPRIO_DIM, "norm_type": C.ACTION_PROPRIO_NORMALIZATION_TYPE.value})
     if state_dict is None:
         log(f"[finetune] no checkpoint at `{cfg.vla_path}` is loadable offline: using seeded random weights of the architecture")
-        state_dict = random_state_dict(model_config, dev, seed=0, lm_head=False)
+        state_dict = random_state_dict(model_config, dev, seed=0, lm_head=False, film=cfg.use_film, diffusion=cfg.use_diffusion)
     get, has = make_getter(state_dict, dev)
-    engine = VLAEngine(model_config, get, dev, lora=True, use_proprio=cfg.use_proprio, head="l1", has=has)
+    engine = VLAEngine(model_config, get, dev, lora=True, use_proprio=cfg.use_proprio, head="diffusion" if cfg.use_diffusion else "l1",
+                       use_film=cfg.use_film, has=has)
+    if cfg.use_diffusion:   # DiffusionActionHead.sample_noisy_actions (action_heads.py:167-197), host side
+        from ..diffusion import DDIMScheduler, SinusoidalPositionalEncoding
+
+        sched, time_enc = DDIMScheduler(cfg.num_diffusion_steps), SinusoidalPositionalEncoding(model_config.llm_dim)
+        noise_gen = torch.Generator().manual_seed(7 + rank)
     log(f"# total trainable params: {engine.num_trainable()}")
     reducer = GradReducer(engine.stores, world) if world > 1 else None
     engine.attach_reducer(reducer, overlap=cfg.grad_accumulation_steps == 1)   # overlap only when every backward ends a step
@@ -199,7 +217,14 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
     for batch_idx, batch in enumerate(dataset):
         if not cfg.use_proprio:
             batch = {**batch, "proprio": None}
-        loss_sum, count, _ = engine.train_step_fwd_bwd(batch, loss_scale=1.0 / cfg.grad_accumulation_steps)
+        diffusion = None
+        if cfg.use_diffusion:
+            gt = batch["actions"].to("cpu", torch.float32)
+            noise = torch.randn(gt.shape, generator=noise_gen).to(torch.bfloat16).float()
+            tsteps = torch.randint(0, cfg.num_diffusion_steps, (gt.shape[0],), generator=noise_gen)
+            diffusion = dict(noise=noise, noisy_actions=sched.add_noise(gt, noise, tsteps).to(torch.bfloat16),
+                             timestep_emb=time_enc(tsteps.float()).to(torch.bfloat16))
+        loss_sum, count, _ = engine.train_step_fwd_bwd(batch, loss_scale=1.0 / cfg.grad_accumulation_steps, diffusion=diffusion)
         gradient_step_idx = batch_idx // cfg.grad_accumulation_steps
         log_step = gradient_step_idx if not cfg.resume else cfg.resume_step + gradient_step_idx
         if (batch_idx + 1) % cfg.grad_accumulation_steps == 0:

@@ -28,7 +28,7 @@ def make_getter(sd: Dict[str, torch.Tensor], device) -> tuple[Callable[[str], to
 
 
 def random_state_dict(cfg: VLAConfig, device, seed: int = 0, *, lora: bool = True, diffusion: bool = False, lm_head: bool = True,
-                      dtype=BF16) -> Dict[str, torch.Tensor]:
+                      film: bool = False, dtype=BF16) -> Dict[str, torch.Tensor]:
     """Seeded random weights of the configured architecture, generated ON DEVICE (no checkpoint exists offline; SURVEY.md
     section 8d config 3: N(0, 0.02)-style init, norm weights ~1, LayerScale 0.1, LoRA A ~ N(0, 1/r), B perturbed from 0)."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -71,6 +71,9 @@ def random_state_dict(cfg: VLAConfig, device, seed: int = 0, *, lora: bool = Tru
             if vc.layerscale:
                 sd[p + "ls1.scale_factor"] = (0.1 + 0.02 * torch.randn(vc.dim, generator=g, device=device)).to(dtype)
                 sd[p + "ls2.scale_factor"] = (0.1 + 0.02 * torch.randn(vc.dim, generator=g, device=device)).to(dtype)
+            if film:
+                lin(p + "scale", vc.dim, cfg.llm_dim, with_lora=False, s=0.01)
+                lin(p + "shift", vc.dim, cfg.llm_dim, with_lora=False, s=0.01)
     vis, D = cfg.vision_dim, cfg.llm_dim
     lin("projector.fc1", 4 * vis, vis)
     lin("projector.fc2", D, 4 * vis)

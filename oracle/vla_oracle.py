@@ -580,8 +580,8 @@ def random_state_dict(cfg: OracleConfig, seed: int = 0, lora: bool = True, film:
                 sd[p + "ls1.scale_factor"] = (0.1 + 0.02 * torch.randn(vc.dim, generator=g)).to(dtype)
                 sd[p + "ls2.scale_factor"] = (0.1 + 0.02 * torch.randn(vc.dim, generator=g)).to(dtype)
             if film:
-                lin(p + "scale", vc.dim, cfg.llm_dim, with_lora=False, s=0.01)
-                lin(p + "shift", vc.dim, cfg.llm_dim, with_lora=False, s=0.01)
+                lin(p + "scale", vc.dim, cfg.llm_dim, with_lora=False, s=0.03)
+                lin(p + "shift", vc.dim, cfg.llm_dim, with_lora=False, s=0.03)
     vis = cfg.dino.dim + cfg.siglip.dim
     lin("projector.fc1", 4 * vis, vis)
     lin("projector.fc2", cfg.llm_dim, 4 * vis)

@@ -134,3 +134,28 @@ def test_finetune_loop(world, tmp_path, monkeypatch):
     assert "action_head--2_checkpoint.pt" in names and "proprio_projector--2_checkpoint.pt" in names and "lora_adapter" in names
     head_sd = torch.load(ck[0] / "action_head--2_checkpoint.pt", weights_only=True)
     assert "model.fc1.weight" in head_sd and head_sd["model.fc1.weight"].shape == (world["cfg"].llm_dim, 7 * world["cfg"].llm_dim)
+
+
+def test_finetune_config5_shapes(world, tmp_path):
+    """BASELINE.json config 5 ingredients together: ALOHA constants (chunk 25 x action dim 14, proprio 14), 3 images,
+    FiLM + diffusion head, through the fine-tune driver (reduced-size model)."""
+    ft, config_mod, C = load("openvla-oft_amd.vla_scripts.finetune"), load("openvla-oft_amd.config"), load("openvla-oft_amd.prismatic.vla.constants")
+    C.set_platform("aloha")
+    try:
+        cfg = ft.FinetuneConfig(run_root_dir=tmp_path, dataset_name="aloha_scoop_x_into_bowl", batch_size=2, num_images_in_input=3, use_proprio=True,
+                                use_l1_regression=False, use_diffusion=True, num_diffusion_steps=50, use_film=True, max_steps=3, wandb_log_freq=1,
+                                save_freq=2)
+        base = world["cfg"]
+        mc = config_mod.VLAConfig(**{**base.__dict__, "num_images": 3})
+        hist = ft.finetune(cfg, model_config=mc, log=lambda *_: None,
+                           dataset=(world["synth"].make_batch(2, seed=s, prompt_lens=[9, 7], image_size=56, chunk=25, action_dim=14, proprio_dim=14,
+                                                              num_images=3) for s in range(50)))
+        assert len(hist["loss_value"]) == 3 and all(np.isfinite(hist["loss_value"]))
+        ck = list(tmp_path.glob("*--2_chkpt"))[0]
+        names = sorted(p.name for p in ck.iterdir())
+        assert {"action_head--2_checkpoint.pt", "noisy_action_projector--2_checkpoint.pt", "proprio_projector--2_checkpoint.pt",
+                "vision_backbone--2_checkpoint.pt"} <= set(names)
+        vb = torch.load(ck / "vision_backbone--2_checkpoint.pt", weights_only=True)
+        assert any(k.endswith("blocks.0.scale.weight") for k in vb)
+    finally:
+        C.set_platform("libero")

@@ -89,10 +89,22 @@ def test_gemm_film_epilogue(ops, dev):
     Bn, rows, N, K = 3, 50, 128, 64
     a, b = rnd(Bn * rows, K, dev=dev), rnd(N, K, dev=dev, scale=0.2)
     res, gamma, beta = rnd(Bn * rows, N, dev=dev), rnd(Bn, N, dev=dev, scale=0.3), rnd(Bn, N, dev=dev)
-    out = ops.gemm(a, b, residual=res, film=(gamma, beta, rows))
+    pre = torch.empty((Bn * rows, N), dtype=BF, device=dev)
+    out = ops.gemm(a, b, residual=res, film=(gamma, beta, rows), c_pre=pre)
     x = ((a.float() @ b.float().T).to(BF).float() + res.float()).to(BF).float().view(Bn, rows, N)
     ref = ((x * (1 + gamma.float()).to(BF).float()[:, None]).to(BF).float() + beta.float()[:, None]).to(BF).view(Bn * rows, N)
     close(out, ref, what="film epilogue")
+    close(pre, x.view(Bn * rows, N).to(BF), what="pre-FiLM save")
+    # backward of the modulation
+    dy = rnd(Bn * rows, N, dev=dev)
+    dy0 = dy.clone()
+    dg = torch.zeros((Bn, N), dtype=torch.float32, device=dev)
+    db = torch.zeros((Bn, N), dtype=torch.float32, device=dev)
+    ops.film_bwd(dy, pre, gamma, dg, db, Bn, rows)
+    d3, p3 = dy0.float().view(Bn, rows, N), pre.float().view(Bn, rows, N)
+    close(dg, (d3 * p3).sum(1), tol=2e-3, mean_tol=3e-4, what="film dgamma")
+    close(db, d3.sum(1), tol=2e-3, mean_tol=3e-4, what="film dbeta")
+    close(dy, (d3 * (1 + gamma.float()).to(BF).float()[:, None]).reshape(Bn * rows, N), what="film dx")
 
 
 @pytest.mark.parametrize("tile", [0, 10, 11, 14])
