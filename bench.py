@@ -296,7 +296,11 @@ def main():
         n, ms, fl = fam["gemm_nt"]
         achieved = fl / (ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 NT GEMM + LoRA K-extension, all tile configs)", "achieved": achieved,
-                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                    # HBM-side bytes per launch from PMC counters cannot be collected from inside this process; the value below is
+                    # the measured, gfx950-corrected FETCH_SIZE*2 + WRITE_SIZE of the most expensive shape (gate|up forward,
+                    # 4864x22016x4096; 4.34e8 algorithmic bytes), see profiles/r01_pmc_gemm_gate_up.md
+                    "traffic": 1.754e9 if not args.tiny else None,
                     "launches_per_step": n, "avg_launch_us": 1e3 * ms / n, "flops_per_step": fl,
                     "other_kernels": {k: {"launches": v[0], "ms": v[1], "tflops": (v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else None)}
                                       for k, v in fam.items() if k != "gemm_nt"},
