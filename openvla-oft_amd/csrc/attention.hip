@@ -16,6 +16,7 @@
 // into rows of head_dim_padded + 16 elements: that stride makes both the ds_read_b128 row reads and the transposed
 // reads bank-conflict free for head_dim 128.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -61,28 +62,29 @@ OVLA_DEV bf16x8_bits gload8(const bf16_bits* base, int64_t stride, int row, int 
   return *reinterpret_cast<const bf16x8_bits*>(base + (int64_t)row * stride + col);
 }
 
-template <int DP>
+template <int DP, int NTHREADS = 256>
 struct TileStage {
   static constexpr int CH = DP / 8;              // 16-byte chunks per row
-  static constexpr int PER_THREAD = BKV * CH / 256;
+  static constexpr int TOTAL = BKV * CH;
+  static constexpr int PER_THREAD = (TOTAL + NTHREADS - 1) / NTHREADS;
   static constexpr int STRIDE = DP + 16;
   bf16x8_bits r[PER_THREAD];
   OVLA_DEV void load(const bf16_bits* base, int64_t stride, int row0, int row_last, int hd, int tid) {
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i) {
-      const int id = tid + 256 * i;
+      const int id = tid + NTHREADS * i;
       const int rr = id / CH, ch = id % CH;
       int gr = row0 + rr;
       gr = gr < row_last ? gr : row_last;
-      r[i] = gload8(base, stride, gr, ch * 8, hd);
+      r[i] = (TOTAL % NTHREADS == 0 || id < TOTAL) ? gload8(base, stride, gr, ch * 8, hd) : zero8();
     }
   }
   OVLA_DEV void store(bf16_bits* tile, int tid) const {
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i) {
-      const int id = tid + 256 * i;
+      const int id = tid + NTHREADS * i;
       const int rr = id / CH, ch = id % CH;
-      *reinterpret_cast<bf16x8_bits*>(tile + rr * STRIDE + ch * 8) = r[i];
+      if (TOTAL % NTHREADS == 0 || id < TOTAL) *reinterpret_cast<bf16x8_bits*>(tile + rr * STRIDE + ch * 8) = r[i];
     }
   }
 };
@@ -90,21 +92,24 @@ struct TileStage {
 OVLA_DEV short f2bf_s(float f) { return (short)f2bf(f); }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int DP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
   constexpr int KS = DP / 32;   // contraction steps over head_dim
   constexpr int DT = DP / 16;   // output d tiles
   constexpr int STRIDE = DP + 16;
-  __shared__ __attribute__((aligned(16))) bf16_bits Ks[BKV * STRIDE];
-  __shared__ __attribute__((aligned(16))) bf16_bits Vs[BKV * STRIDE];
+  constexpr int NTH = 64 * NW;
+  constexpr int BQW = 16 * NW;  // query rows per workgroup (NW = 8: 128 rows share every K/V tile)
+  // K/V tiles are double buffered in LDS: tile t+1 is written while tile t is still being read -> ONE barrier per tile
+  __shared__ __attribute__((aligned(16))) bf16_bits Ks[2][BKV * STRIDE];
+  __shared__ __attribute__((aligned(16))) bf16_bits Vs[2][BKV * STRIDE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQ;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQW;
   const int qrow = q0 + wave * 16 + (lane & 15);
   const int qrow_c = qrow < p.S ? qrow : p.S - 1;
   const int kvlen = p.kv_len ? p.kv_len[b] : p.S;
   int kv_end = kvlen < p.S ? kvlen : p.S;
-  if (p.causal) kv_end = kv_end < (q0 + BQ) ? kv_end : (q0 + BQ);
+  if (p.causal) kv_end = kv_end < (q0 + BQW) ? kv_end : (q0 + BQW);
   const int ntiles = (kv_end + BKV - 1) / BKV;
 
   const bf16_bits* Qb = p.Q + (int64_t)b * p.S * p.q_stride + (int64_t)h * p.hd;
@@ -121,20 +126,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   float m_run = -INFINITY, l_run = 0.f;
   const float sl2 = p.scale * LOG2E;
 
-  TileStage<DP> kst, vst;
+  // Register-staged prefetch: tile t+1 sits in registers while tile t is consumed; it is written to the other LDS
+  // buffer after tile t's MFMAs and tile t+2's loads are issued right behind.  (Measured: the loop is bound by this
+  // global -> register -> LDS latency chain -- with all math removed it keeps 60 % of its time -- so occupancy matters
+  // more than anything else here: a second register set (2-tile distance) cost 64 VGPRs and ran 1.4x SLOWER.)
+  TileStage<DP, NTH> kst, vst;
   if (ntiles > 0) {
     kst.load(Kb, p.k_stride, 0, p.S - 1, p.hd, tid);
     vst.load(Vb, p.v_stride, 0, p.S - 1, p.hd, tid);
-  }
-  for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();
-    kst.store(Ks, tid);
-    vst.store(Vs, tid);
-    __syncthreads();
-    if (t + 1 < ntiles) {
-      kst.load(Kb, p.k_stride, (t + 1) * BKV, p.S - 1, p.hd, tid);
-      vst.load(Vb, p.v_stride, (t + 1) * BKV, p.S - 1, p.hd, tid);
+    kst.store(Ks[0], tid);
+    vst.store(Vs[0], tid);
+    if (ntiles > 1) {
+      kst.load(Kb, p.k_stride, BKV, p.S - 1, p.hd, tid);
+      vst.load(Vb, p.v_stride, BKV, p.S - 1, p.hd, tid);
     }
+  }
+  __syncthreads();
+
+  auto tile = [&](int t, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    const bf16_bits* Kt = Ks[t & 1];
+    const bf16_bits* Vt = Vs[t & 1];
     // S^T = K . Q^T : accS[nt][j] = S[q = lane&15][key = 16 nt + 4 g + j]
     f32x4 accS[4];
 #pragma unroll
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       accS[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < KS; ++s)
-        accS[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, nt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), qf[s],
+        accS[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Kt, nt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), qf[s],
                                                            accS[nt], 0, 0, 0);
     }
     const int kbase = t * BKV;
@@ -151,9 +163,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int key = kbase + nt * 16 + 4 * g + j;
-        const bool ok = key < kvlen && (!p.causal || key <= qrow);
-        const float sv = ok ? accS[nt][j] * sl2 : -INFINITY;
+        float sv = accS[nt][j] * sl2;
+        if constexpr (MASK) {
+          const int key = kbase + nt * 16 + 4 * g + j;
+          const bool ok = key < kvlen && (!p.causal || key <= qrow);
+          sv = ok ? sv : -INFINITY;
+        }
         accS[nt][j] = sv;
         mx = fmaxf(mx, sv);
       }
@@ -188,9 +203,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       }
 #pragma unroll
       for (int d = 0; d < DT; ++d)
-        accO[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vs, 32 * s2, d * 16, STRIDE, lane), pf, accO[d], 0, 0, 0);
+        accO[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vt, 32 * s2, d * 16, STRIDE, lane), pf, accO[d], 0, 0, 0);
     }
-  }
+    if (t + 1 < ntiles) {   // tile t+1 (in registers since the previous iteration) -> the other LDS buffer; fetch tile t+2
+      kst.store(Ks[(t + 1) & 1], tid);
+      vst.store(Vs[(t + 1) & 1], tid);
+      if (t + 2 < ntiles) {
+        kst.load(Kb, p.k_stride, (t + 2) * BKV, p.S - 1, p.hd, tid);
+        vst.load(Vb, p.v_stride, (t + 2) * BKV, p.S - 1, p.hd, tid);
+      }
+    }
+    __syncthreads();
+  };
+  // interior tiles (every key valid for every row of this workgroup) run a body with NO mask code at all; only the last
+  // tile(s) -- key padding tail, causal diagonal -- take the masked body
+  int n_free = kvlen / BKV;
+  if (p.causal) n_free = n_free < (q0 / BKV) ? n_free : (q0 / BKV);   // tiles whose last key precedes the first query row
+  if (n_free > ntiles) n_free = ntiles;
+  for (int t = 0; t < n_free; ++t) tile(t, std::false_type{});
+  for (int t = n_free; t < ntiles; ++t) tile(t, std::true_type{});
   l_run += __shfl_xor(l_run, 16, 64);
   l_run += __shfl_xor(l_run, 32, 64);
   const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
@@ -496,11 +527,20 @@ extern "C" int ovla_attn_fwd(const ovla_attn_fwd_args* a, void* stream_) {
   p.Q = (const bf16_bits*)a->Q; p.K = (const bf16_bits*)a->K; p.V = (const bf16_bits*)a->V; p.Oout = (bf16_bits*)a->O;
   p.q_stride = a->q_stride; p.k_stride = a->k_stride; p.v_stride = a->v_stride; p.o_stride = a->o_stride;
   p.lse = a->lse; p.kv_len = a->kv_len; p.B = a->B; p.H = a->H; p.S = a->S; p.hd = a->head_dim; p.causal = a->causal; p.scale = a->scale;
-  const dim3 grid(cdiv(a->S, BQ), a->H, a->B);
-  switch (a->head_dim) {
-    case 64: hipLaunchKernelGGL(attn_fwd_kernel<64>, grid, dim3(256), 0, stream, p); break;
-    case 72: hipLaunchKernelGGL(attn_fwd_kernel<96>, grid, dim3(256), 0, stream, p); break;
-    default: hipLaunchKernelGGL(attn_fwd_kernel<128>, grid, dim3(256), 0, stream, p); break;
+  if (a->S > 64) {   // 8 waves x 16 query rows = 128 rows per workgroup share every K/V tile
+    const dim3 grid(cdiv(a->S, 128), a->H, a->B);
+    switch (a->head_dim) {
+      case 64: hipLaunchKernelGGL((attn_fwd_kernel<64, 8>), grid, dim3(512), 0, stream, p); break;
+      case 72: hipLaunchKernelGGL((attn_fwd_kernel<96, 8>), grid, dim3(512), 0, stream, p); break;
+      default: hipLaunchKernelGGL((attn_fwd_kernel<128, 8>), grid, dim3(512), 0, stream, p); break;
+    }
+  } else {
+    const dim3 grid(cdiv(a->S, BQ), a->H, a->B);
+    switch (a->head_dim) {
+      case 64: hipLaunchKernelGGL((attn_fwd_kernel<64, 4>), grid, dim3(256), 0, stream, p); break;
+      case 72: hipLaunchKernelGGL((attn_fwd_kernel<96, 4>), grid, dim3(256), 0, stream, p); break;
+      default: hipLaunchKernelGGL((attn_fwd_kernel<128, 4>), grid, dim3(256), 0, stream, p); break;
+    }
   }
   OVLA_CHECK_LAUNCH("ovla_attn_fwd");
   return OVLA_OK;
