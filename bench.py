@@ -280,6 +280,30 @@ def main():
     value = world * args.batch * args.steps / elapsed
     final_loss = loss_sum.item() / (args.batch * cfg.chunk * cfg.action_dim)
 
+    # ---- BASELINE.json configs[1]: single-chunk inference, batch 1 (same engine, no backward); rank 0 only, no collectives ----
+    infer = None
+    if rank == 0:
+        b1 = synth.make_batch(1, seed=77, num_images=cfg.num_images, chunk=cfg.chunk, action_dim=cfg.action_dim, proprio_dim=cfg.proprio_dim)
+        b1["pixel_values"] = b1["pixel_values"].to(dev, torch.bfloat16)
+        b1["proprio"] = b1["proprio"].to(dev, torch.bfloat16).reshape(1, -1)
+
+        def infer_once():
+            out = eng.forward(b1["input_ids"], b1["attention_mask"], b1["pixel_values"], b1["labels"], proprio=b1["proprio"], train=False)
+            ah, _ = eng.gather_action_hidden(out["hidden"], out["action_rows"])
+            return eng.head.fwd(ah)[0]
+
+        for _ in range(3):
+            infer_once()
+        torch.cuda.synchronize()
+        ti = time.perf_counter()
+        n_inf = 20
+        for _ in range(n_inf):
+            pred1 = infer_once()
+        torch.cuda.synchronize()
+        ms_inf = 1e3 * (time.perf_counter() - ti) / n_inf
+        infer = {"workload": "BASELINE.json configs[1]: OpenVLA-7B L1-regression inference, 2x224x224 images + proprio, bf16, batch 1 (one 8x7 action chunk per forward)",
+                 "ms_per_chunk": ms_inf, "chunks_per_s": 1e3 / ms_inf, "actions_per_s": 1e3 / ms_inf * cfg.chunk}
+
     roofline = cpu = None
     # dominant kernel (gemm_nt) timed launch by launch with HIP events on the launch stream over one more step.  EVERY rank
     # runs the step (it contains the gradient collectives); only rank 0 records events.
@@ -320,7 +344,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: LoRA r=32 fine-tune step (fwd+bwd+AdamW), 2x224x224 images + proprio, L1 head" + (" [TINY MODEL - not a benchmark]" if args.tiny else ""),
                        "global_batch": world * args.batch, "seq_len": S, "parallelism": f"dp{world}", "mask_mode": cfg.mask_mode,
                        "final_loss": final_loss},
-            "roofline": roofline, "cpu_baseline": cpu}))
+            "roofline": roofline, "cpu_baseline": cpu, "inference_batch1": infer}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -15,6 +15,7 @@
 //     one row: the epilogue does 8-byte loads/stores;
 //   * block ids are remapped so each XCD (private L2) owns a contiguous band of tiles, grouped 8 tile-rows deep.
 #include "common.h"
+#include <type_traits>
 #include <stdarg.h>
 
 namespace {
@@ -37,7 +38,7 @@ struct GemmParams {
   float* ws;
   int tiles_m, tiles_n, T1, T2;
   int fast_addr;  // 1: every staged byte offset fits in 32 bits (host-checked)
-  int dbg;  // timing ablations (tools/gemm_ablate.py): bit0 = stage only the first two K tiles, bit1 = read fragments once
+  int dbg;  // timing ablations (tools/gemm_ablate.py): bit0 = stage only the first two K tiles, bit1 = read fragments once, bit2 = every workgroup stages tile (0,0): all L2 hits
   int full_tiles, rem_tiles, rem_splits;  // hybrid schedule: tiles >= full_tiles are split rem_splits ways along K
 };
 
@@ -85,6 +86,14 @@ OVLA_DEV void stage_tile_fast(const char* __restrict__ base_k /* uniform: matrix
     const int rbase = (wave * PER_WAVE + i) * 8;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base_k + off[i]),
                                      (__attribute__((address_space(3))) void*)(lds_tile + rbase * BK), 16, 0, 0);
+  }
+}
+
+template <int N, int I = 0, typename F>
+OVLA_DEV void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<N, I + 1>(f);
   }
 }
 
@@ -206,8 +215,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   uint32_t offA[BM / 8 / NW], offB[BN / 8 / NW];
-  stage_offsets<BM, NW>(offA, p.lda, m0, p.M - 1, wave, lane);
-  stage_offsets<BN, NW>(offB, p.ldb, n0, p.N - 1, wave, lane);
+  stage_offsets<BM, NW>(offA, p.lda, (p.dbg & 4) ? 0 : m0, p.M - 1, wave, lane);
+  stage_offsets<BN, NW>(offB, p.ldb, (p.dbg & 4) ? 0 : n0, p.N - 1, wave, lane);
   const int t_fast = p.fast_addr ? p.K / BK : 0;   // K tiles that lie entirely inside [0, K): no zero-chunk select needed
 
   auto stage = [&](int t, int buf) {
@@ -227,44 +236,100 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     }
   };
 
-  if (t_begin < t_end) stage(t_begin, 0);
-  for (int t = t_begin; t < t_end; ++t) {
+  // MFMA rows r = (k-substep s, m-tile i).  Fragment reads run one row ahead of the MFMAs, and the LAST row of every K
+  // tile is deferred across the barrier: its fragments stay in registers (a_def, b1) and its NT MFMAs issue right after
+  // the next tile's first fragment reads, so the matrix pipe has work while those reads (and the LDS-DMA issue) are in
+  // flight instead of every wave draining its pipeline at each barrier.
+  constexpr int BPR = (NT + MT - 1) / MT;  // next-substep B fragments fetched per row
+  const int arow = wm * WTM + (lane & 15), brow = wn * WTN + (lane & 15), cq = lane >> 4;
+  bf16x8_bits b0[NT], b1[NT];
+  bf16x8_bits a_def = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < NT; ++j) b1[j] = a_def;
+
+  // LDS-DMA issue is expensive for the issuing wave (~60-150 cycles per 1 KiB piece), so the next tile's pieces are not
+  // issued as one burst after the barrier (all 8 waves stuck in issue, matrix pipe idle) but spread over the first MT row
+  // slots, PPS per slot, where the SIMD partner's MFMAs cover them.  Only K tiles on the fast-address path are spread
+  // (`SPREAD` loop); the K tail and the LoRA K-extension tiles keep the simple stage-after-barrier scheme.
+  constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW, PP = PA + PB;
+  constexpr int PPS = (PP + MT - 1) / MT;
+  auto tile_body = [&](const int t, auto spread_tag) {
+    constexpr bool SPREAD = decltype(spread_tag)::value;
     const int buf = (t - t_begin) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA for tile t has landed
     __syncthreads();                                   // ... everyone's has; and buf^1 is no longer being read
-    if (t + 1 < t_end && !((p.dbg & 1) && t > t_begin)) stage(t + 1, buf ^ 1);
+    if constexpr (!SPREAD) {
+      if (t + 1 < t_end && !((p.dbg & 1) && t > t_begin)) stage(t + 1, buf ^ 1);
+    }
     const bf16_bits* sA = smem + ((p.dbg & 2) ? 0 : buf) * TILE_ELEMS;
     const bf16_bits* sB = sA + BM * BK;
-    // MFMA rows r = (k-substep s, m-tile i).  Fragment reads run one row ahead of the MFMAs: while row r's NT MFMAs
-    // issue, the A fragment of row r+1 and a slice of the NEXT substep's B fragments are in flight, so the two waves
-    // sharing a SIMD do not both sit in an un-overlapped LDS phase after every barrier.
-    constexpr int BPR = (NT + MT - 1) / MT;  // next-substep B fragments fetched per row
-    const int arow = wm * WTM + (lane & 15), brow = wn * WTN + (lane & 15), cq = lane >> 4;
-    bf16x8_bits b0[NT], b1[NT];
+    bf16_bits* nA = smem + (buf ^ 1) * TILE_ELEMS;
+    bf16_bits* nB = nA + BM * BK;
+    const char* gA = reinterpret_cast<const char*>(Ablk) + (int64_t)(t + 1) * (BK * 2);
+    const char* gB = reinterpret_cast<const char*>(p.B) + (int64_t)(t + 1) * (BK * 2);
+    auto pieces = [&](auto slot_tag) {
+      constexpr int SLOT = decltype(slot_tag)::value;
+#pragma unroll
+      for (int q = SLOT * PPS; q < (SLOT + 1) * PPS && q < PP; ++q) {
+        if (q < PA)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + offA[q < PA ? q : 0]),
+                                           (__attribute__((address_space(3))) void*)(nA + (wave * PA + q) * 8 * BK), 16, 0, 0);
+        else
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + offB[q >= PA ? q - PA : 0]),
+                                           (__attribute__((address_space(3))) void*)(nB + (wave * PB + (q - PA)) * 8 * BK), 16, 0, 0);
+      }
+    };
+    constexpr int NP0 = PP < PPS ? PP : PPS;
 #pragma unroll
     for (int j = 0; j < NT; ++j) b0[j] = lds_frag(sB, brow + j * 16, cq);
     bf16x8_bits a_cur = lds_frag(sA, arow, cq);
+    if constexpr (SPREAD) pieces(std::integral_constant<int, 0>{});
     __builtin_amdgcn_s_setprio(1);
+    // deferred last row of the previous tile (zeros on the first pass)
 #pragma unroll
-    for (int r = 0; r < 2 * MT; ++r) {
-      const int sub = r / MT, i = r % MT;
-      bf16x8_bits a_nxt = a_cur;
-      if (r + 1 < 2 * MT) a_nxt = lds_frag(sA, arow + ((r + 1) % MT) * 16, ((r + 1) / MT) * 4 + cq);
-      if (sub == 0) {
+    for (int j = 0; j < NT; ++j)
+      acc[MT - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a_def, acc[MT - 1][j], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);
+    if constexpr (SPREAD) __builtin_amdgcn_sched_group_barrier(0x020, NP0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+    auto row = [&](auto r_tag) {
+      constexpr int r = decltype(r_tag)::value;
+      constexpr int sub = r / MT, i = r % MT;
+      bf16x8_bits a_nxt = lds_frag(sA, arow + ((r + 1) % MT) * 16, ((r + 1) / MT) * 4 + cq);
+      if constexpr (sub == 0) {
 #pragma unroll
         for (int jj = 0; jj < BPR; ++jj)
           if (i * BPR + jj < NT) b1[i * BPR + jj] = lds_frag(sB, brow + (i * BPR + jj) * 16, 4 + cq);
       }
+      constexpr int NPR = (r + 1 < MT) ? (((r + 2) * PPS <= PP) ? PPS : (((r + 1) * PPS < PP) ? PP - (r + 1) * PPS : 0)) : 0;
+      if constexpr (SPREAD && NPR > 0) pieces(std::integral_constant<int, r + 1>{});
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sub == 0 ? b0[j] : b1[j], a_cur, acc[i][j], 0, 0, 0);
-      if (sub == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1 + BPR, 0);  // DS reads of the next row
+      if constexpr (sub == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1 + BPR, 0);  // DS reads of the next row
       else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if constexpr (SPREAD && NPR > 0) __builtin_amdgcn_sched_group_barrier(0x020, NPR, 0);  // LDS-DMA pieces of the next tile
       __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);                       // this row's MFMAs
       a_cur = a_nxt;
-    }
+    };
+    static_for<2 * MT - 1>(row);
+    a_def = a_cur;   // row 2*MT-1 (substep 1, m-tile MT-1): issued after the next barrier
     __builtin_amdgcn_s_setprio(0);
+  };
+
+  if (t_begin < t_end) stage(t_begin, 0);
+  int t = t_begin;
+  {
+    const int lim = t_end < t_fast ? t_end : t_fast;   // spread loop: tile t+1 exists and is a fast-address tile
+    if constexpr (NW >= 8) {   // 4-wave configs run 2 workgroups per CU, which already interleave; spreading only costs them
+      if (!(p.dbg & 1))
+        for (; t + 1 < lim; ++t) tile_body(t, std::true_type{});
+    }
   }
+  for (; t < t_end; ++t) tile_body(t, std::false_type{});
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+    acc[MT - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a_def, acc[MT - 1][j], 0, 0, 0);
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // MFMA layout (operands swapped): lane owns C[m][n..n+3] with m = tile row (lane&15), n = 4*(lane>>4).

@@ -1,5 +1,6 @@
 """Timing-only ablations of gemm_nt (results are wrong by construction): where do the main loop's cycles go?
-tile + 1000: no global->LDS traffic after the first two K tiles; tile + 2000: every K tile re-reads LDS buffer 0 only."""
+tile + 1000: no global->LDS traffic after the first two K tiles; tile + 2000: every K tile re-reads LDS buffer 0 only;
+tile + 4000: every workgroup stages tile (0, 0) (global loads always hit L2)."""
 import importlib, sys
 from pathlib import Path
 import torch
@@ -14,12 +15,12 @@ def bench(fn, iters=20):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-for (m, n, k) in [(4864, 12288, 4096), (4864 * 0 + 4096, 4096, 4096), (4864, 22016, 4096)]:
+for (m, n, k) in [(4864, 22016, 4096), (4864, 12288, 4096), (4096, 4096, 4096), (4864, 4096, 11008), (4864, 4096, 4096), (4864, 22016, 4096)]:
     a = torch.randn(m, k, device=dev).to(torch.bfloat16); b = torch.randn(n, k, device=dev).to(torch.bfloat16)
     out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
     fl = 2.0 * m * n * k
     row = []
-    for t in (17, 10, 15, 11, 12):
+    for t in (17, 117, 1017, 4017, 1, 101, 3):
         ms = bench(lambda: ops.gemm(a, b, out=out, tile=t))
         row.append(f"tile{t}: {fl / ms / 1e9:6.0f}")
     print(m, n, k, " | ".join(row), flush=True)
