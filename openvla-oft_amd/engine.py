@@ -18,6 +18,8 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -692,15 +694,30 @@ class VLAEngine:
         I = C // 6
         Np, vd = cfg.dino.n_patches, cfg.vision_dim
         feats = torch.empty((B, I * Np, vd), dtype=BF16, device=self.device)   # == [(B*I), Np, vd]: (b, img) is the tower batch
-        tower_saved = []
-        for tower, c0, col0 in ((self.dino, 0, 0), (self.siglip, 3, cfg.dino.dim)):
+        tower_saved = [None, None]
+
+        def run_tower(k, tower, c0, col0):
             vc = tower.vc
             T = vc.n_patches + vc.n_prefix
             tok, sv = tower.fwd(pixel_values, c0, I, train, film_avg)
             # drop prefix tokens, concat features on dim 2 and images on dim 1 (modeling_prismatic.py:221-227)
             ops.copy_rows(tok, feats, B * I, Np, vc.dim, src_batch_stride=T * vc.dim, src_row0=vc.n_prefix, src_ld=vc.dim,
                           dst_batch_stride=Np * vd, dst_row0=0, dst_ld=vd, dst_col0=col0)
-            tower_saved.append(sv)
+            tower_saved[k] = sv
+
+        # The towers are independent until the feature concat: SigLIP runs on a second HIP stream beside DINOv2, so the
+        # tails of one tower's mid-sized GEMMs and its latency-bound small kernels overlap with the other's work.
+        side = self._side_stream()
+        if side is not None:
+            main = torch.cuda.current_stream(self.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                run_tower(1, self.siglip, 3, cfg.dino.dim)
+            run_tower(0, self.dino, 0, 0)
+            main.wait_stream(side)
+        else:
+            run_tower(0, self.dino, 0, 0)
+            run_tower(1, self.siglip, 3, cfg.dino.dim)
         f2 = feats.view(B * I * Np, vd)
         z1 = torch.empty((f2.shape[0], 4 * vd), dtype=BF16, device=self.device) if train else None
         h1, s1 = self.proj[0].fwd(f2, act=ops.ACT_GELU, c_pre=z1)
@@ -717,8 +734,7 @@ class VLAEngine:
         d = self.proj[2].bwd(dpatches, s3)
         d = self.proj[1].bwd(ops.act_bwd(z2, d, ops.ACT_GELU), s2)
         dfeat = self.proj[0].bwd(ops.act_bwd(z1, d, ops.ACT_GELU), s1)            # [B*I*Np, vd]
-        # SigLIP first: its parameters precede DINOv2's in the backward-ordered flat gradient buffer
-        for k, (tower, col0) in reversed(list(enumerate(((self.dino, 0), (self.siglip, cfg.dino.dim))))):
+        def run_tower(k, tower, col0):
             vc = tower.vc
             T = vc.n_patches + vc.n_prefix
             dtok = torch.zeros((B * I * T, vc.dim), dtype=BF16, device=self.device)
@@ -726,6 +742,26 @@ class VLAEngine:
             ops.copy_rows(dfeat[:, col0: col0 + vc.dim], dtok, B * I, Np, vc.dim, src_batch_stride=Np * vd, src_row0=0, src_ld=vd,
                           dst_batch_stride=T * vc.dim, dst_row0=vc.n_prefix, dst_ld=vc.dim)
             tower.bwd(dtok, tower_saved[k])
+
+        side = self._side_stream()
+        if side is not None:   # same two-stream split as the forward; the towers' gradients live in disjoint buffer ranges
+            main = torch.cuda.current_stream(self.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                run_tower(1, self.siglip, cfg.dino.dim)
+            run_tower(0, self.dino, 0)
+            main.wait_stream(side)   # before dfeat is released and before the optimizer / gradient reducer read the buffers
+        else:
+            run_tower(1, self.siglip, cfg.dino.dim)
+            run_tower(0, self.dino, 0)
+
+    def _side_stream(self):
+        """Second HIP stream for the SigLIP tower (OVLA_VIT_STREAMS=1 disables the split)."""
+        if os.environ.get("OVLA_VIT_STREAMS", "2") == "1":
+            return None
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     # -- the training step pieces -------------------------------------------------------------------------------------------
     def language_average(self, ids_dev, labels_cpu):

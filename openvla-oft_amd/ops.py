@@ -22,10 +22,13 @@ _ws_cache = {}
 
 
 def _workspace(device, nbytes):
-    ws = _ws_cache.get(device)
+    """One scratch buffer per (device, stream): launches on one stream reuse it in stream order; the two vision towers run
+    on different streams and must not share partial-sum slabs."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ws_cache.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty(max(nbytes, _WS_BYTES) // 4, dtype=torch.float32, device=device)
-        _ws_cache[device] = ws
+        _ws_cache[key] = ws
     return ws
 
 

@@ -1,0 +1,44 @@
+"""Per-shape time of every gemm_nt launch in one full 7B LoRA step (HIP events around each launch): which shapes to tune."""
+import importlib, sys, collections
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+load = importlib.import_module
+ops, engine_mod, weights_mod, synth, config_mod = (load("openvla-oft_amd.ops"), load("openvla-oft_amd.engine"), load("openvla-oft_amd.weights"),
+                                                   load("openvla-oft_amd.synthetic"), load("openvla-oft_amd.config"))
+dev = torch.device("cuda:0")
+cfg = config_mod.OPENVLA_7B
+sd = weights_mod.random_state_dict(cfg, dev, seed=0, lm_head=False)
+get, has = weights_mod.make_getter(sd, dev)
+eng = engine_mod.VLAEngine(cfg, get, dev, lora=True, use_proprio=True, head="l1", has=has)
+del sd, get
+batch = synth.make_batch(8, seed=1000, num_images=cfg.num_images, chunk=cfg.chunk, action_dim=cfg.action_dim, proprio_dim=cfg.proprio_dim)
+for k in ("pixel_values", "actions", "proprio"):
+    batch[k] = batch[k].to(dev, torch.bfloat16)
+
+def step():
+    eng.zero_grad(); eng.train_step_fwd_bwd(batch); eng.adamw_step(lr=5e-4); eng.refresh_derived()
+
+for _ in range(2): step()
+records = []
+orig = ops.gemm
+def traced(a, b, **kw):
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(); out = orig(a, b, **kw); e1.record()
+    K2 = kw["b2"].shape[1] if kw.get("b2") is not None else 0
+    records.append(((a.shape[0], b.shape[0], b.shape[1], K2, kw.get("a_group_n", 0)), e0, e1))
+    return out
+ops.gemm = traced
+engine_mod.ops.gemm = traced
+step(); torch.cuda.synchronize()
+agg = collections.defaultdict(lambda: [0, 0.0])
+for key, e0, e1 in records:
+    agg[key][0] += 1; agg[key][1] += e0.elapsed_time(e1)
+tot = sum(v[1] for v in agg.values())
+print(f"total gemm_nt ms {tot:.1f}, launches {len(records)}")
+print(f"{'M':>6} {'N':>6} {'K':>6} {'K2':>4} {'grp':>4} {'n':>5} {'ms':>8} {'us/launch':>10} {'TF':>6}")
+for key, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    M, N, K, K2, g = key
+    G = (N // g) if g else 1
+    fl = 2.0 * M * N * (K + K2)
+    print(f"{M:6d} {N:6d} {K:6d} {K2:4d} {g:4d} {n:5d} {ms:8.2f} {1e3 * ms / n:10.1f} {fl * n / ms / 1e9:6.0f}")
