@@ -642,18 +642,34 @@ static int num_cus() {
   return g_num_cus;
 }
 
-// Picks the K split of the remainder tiles: minimises (last-round time) + (reduce traffic), both in units of seconds.
-static int pick_rem_splits(int rem_tiles, int slots, int T, double tile_flops, double per_slot_rate, double tile_bytes_f32, int64_t ws_floats,
-                           int bm_bn) {
+// Hybrid schedule of one tile config: whole rounds of the chip as full tiles, the partial last round split along K.
+// The same cost model (seconds) picks the split and, in auto mode, the tile config itself.  Constants calibrated on
+// MI355X (tools/gemm_sweep.py): sustained in-loop rate per config and a fixed per-workgroup cost t0 (prologue latency +
+// epilogue), slab traffic at ~5 TB/s (mostly Infinity-Cache resident) + the reduce launch.
+struct HybridPlan { int full_tiles, rem_tiles, rem_splits; double est; };
+
+static HybridPlan plan_hybrid(int M, int N, double ktot, int T, int BM, int BN, int slots, int64_t ws_floats) {
+  const bool big = BM >= 256 && BN >= 256;
+  const double rate = (big ? 1.3e15 : 1.13e15) / slots, t0 = big ? 7e-6 : 4e-6;
+  const int tiles = cdiv(M, BM) * cdiv(N, BN);
+  const double tt = 2.0 * BM * BN * ktot / rate;
+  HybridPlan pl{tiles, 0, 1, 0.0};
+  const int full_rounds = tiles / slots, rem = tiles % slots;
+  pl.est = full_rounds * (tt + t0);
+  if (rem == 0) return pl;
+  double best_t = tt + t0;   // unsplit: one more (partial) round
   int best = 1;
-  double best_t = tile_flops / per_slot_rate;   // unsplit: one more full tile time
-  for (int sp = 2; sp <= 8 && sp * 4 <= T; ++sp) {
-    if ((int64_t)rem_tiles * sp * bm_bn > ws_floats) break;
-    const int rounds = (rem_tiles * sp + slots - 1) / slots;
-    const double t = rounds * (tile_flops / sp) / per_slot_rate + 2.0 * rem_tiles * sp * tile_bytes_f32 / 2.5e12 + 4e-6;
-    if (t < best_t) { best_t = t; best = sp; }
+  if (rem * 4 <= slots * 3 && ws_floats > 0) {
+    for (int sp = 2; sp <= 8 && sp * 4 <= T; ++sp) {
+      if ((int64_t)rem * sp * BM * BN > ws_floats) break;
+      const int rounds = (rem * sp + slots - 1) / slots;
+      const double t = rounds * (tt / sp + t0) + 1.0 * rem * sp * (4.0 * BM * BN) / 5e12 + 5e-6;   // slab writes overlap; the reduce reads them
+      if (t < best_t) { best_t = t; best = sp; }
+    }
   }
-  return best;
+  pl.est += best_t;
+  if (best > 1) { pl.full_tiles = tiles - rem; pl.rem_tiles = rem; pl.rem_splits = best; }
+  return pl;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -681,18 +697,8 @@ int launch_cfg(GemmParams& p, hipStream_t stream, int64_t ws_bytes = 0, bool hyb
   if (hybrid && splits == 1 && p.ws != nullptr) {
     const int bpc = lds <= 80 * 1024 ? 2 : 1;          // workgroups per CU (160 KiB LDS)
     static_assert((size_t)WM * WN * 32 * (BN / WN + 4) * sizeof(float) <= 160 * 1024, "epilogue slabs exceed LDS");
-    const int slots = num_cus() * bpc;
-    const int rem = tiles % slots;
-    if (rem > 0 && rem * 4 <= slots * 3) {
-      const double tile_flops = 2.0 * BM * BN * ((double)p.K + p.K2);
-      const double per_slot = (BM >= 256 && BN >= 256 ? 1.3e15 : 0.95e15) / slots;
-      const int sp = pick_rem_splits(rem, slots, p.T1 + p.T2, tile_flops, per_slot, 4.0 * BM * BN, ws_bytes / 4, BM * BN);
-      if (sp > 1) {
-        p.full_tiles = tiles - rem;
-        p.rem_tiles = rem;
-        p.rem_splits = sp;
-      }
-    }
+    const HybridPlan pl = plan_hybrid(p.M, p.N, (double)p.K + p.K2, p.T1 + p.T2, BM, BN, num_cus() * bpc, ws_bytes / 4);
+    p.full_tiles = pl.full_tiles; p.rem_tiles = pl.rem_tiles; p.rem_splits = pl.rem_splits;
   }
   const unsigned nblk = p.rem_tiles > 0 ? (unsigned)(p.full_tiles + p.rem_tiles * p.rem_splits) : (unsigned)(tiles * splits);
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * WM * WN), lds, stream, p);
@@ -810,8 +816,16 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     if (p.N <= 32 || p.a_group_n == 32) { tile = 5; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 128) * cdiv(p.N, 32)); }
     else if (p.a_group_n > 0) { tile = 1; }
     else if (p.M <= 64 || p.N <= 128) { tile = 2; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 64) * cdiv(p.N, 128)); }
-    else if ((int64_t)cdiv(p.M, 256) * cdiv(p.N, 256) >= 200 && p.K >= 2048 && (p.k2_group_n == 0 || p.k2_group_n % 256 == 0)) { tile = 17; hybrid = true; }
-    else { tile = 1; hybrid = true; }
+    else {   // 256x256 (1 workgroup/CU) or 128x128 (2/CU), whichever the hybrid-schedule cost model predicts faster
+      hybrid = true;
+      tile = 1;
+      if (p.k2_group_n == 0 || p.k2_group_n % 256 == 0) {
+        const double ktot = (double)p.K + p.K2;
+        const HybridPlan big = plan_hybrid(p.M, p.N, ktot, T, 256, 256, num_cus(), wsb / 4);
+        const HybridPlan small = plan_hybrid(p.M, p.N, ktot, T, 128, 128, 2 * num_cus(), wsb / 4);
+        if (big.est < small.est) tile = 17;
+      }
+    }
   }
   switch (tile) {
     case 1: return launch_cfg<128, 128, 2, 2>(p, stream, wsb, hybrid);

@@ -13,7 +13,8 @@ M = 4864
 SHAPES = [("qkv", M, 12288, 4096, 32), ("o", M, 4096, 4096, 32), ("gate_up", M, 22016, 4096, 32), ("down", M, 4096, 11008, 32),
           ("d_qkv", M, 4096, 12288, 96), ("d_gate_up", M, 4096, 22016, 64), ("d_down", M, 11008, 4096, 32),
           ("vit_fc1", 4176, 4096, 1024, 32), ("vit_fc2", 4176, 1024, 4096, 32), ("siglip_qkv", 4096, 3456, 1152, 32),
-          ("proj_fc1", 4096, 8704, 2176, 32), ("lora_t", M, 96, 4096, 0), ("lora_dt", M, 32, 4096, 0), ("head_fc1", 64, 4096, 28672, 0)]
+          ("vit_qkv", 4176, 3072, 1024, 32), ("vit_o", 4176, 1024, 1024, 32), ("siglip_fc1", 4096, 4304, 1152, 32),
+          ("siglip_fc2", 4096, 1152, 4304, 32), ("siglip_o", 4096, 1152, 1152, 32), ("proj_fc1", 4096, 8704, 2176, 32), ("lora_t", M, 96, 4096, 0), ("lora_dt", M, 32, 4096, 0), ("head_fc1", 64, 4096, 28672, 0)]
 
 
 def bench(fn, iters=20):
