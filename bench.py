@@ -194,6 +194,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (reference recipe: 8, LIBERO.md:91-113)")
     ap.add_argument("--tiny", action="store_true", help="reduced-size model (plumbing check only; NOT a valid benchmark number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inference", action="store_true", help="skip the batch-1 inference leg (configs[1])")
     ap.add_argument("--eager-baseline", action="store_true", help="time the stock PyTorch-ROCm eager step instead (BASELINE.md B1) and exit")
     args = ap.parse_args()
 
@@ -280,30 +281,6 @@ def main():
     value = world * args.batch * args.steps / elapsed
     final_loss = loss_sum.item() / (args.batch * cfg.chunk * cfg.action_dim)
 
-    # ---- BASELINE.json configs[1]: single-chunk inference, batch 1 (same engine, no backward); rank 0 only, no collectives ----
-    infer = None
-    if rank == 0:
-        b1 = synth.make_batch(1, seed=77, num_images=cfg.num_images, chunk=cfg.chunk, action_dim=cfg.action_dim, proprio_dim=cfg.proprio_dim)
-        b1["pixel_values"] = b1["pixel_values"].to(dev, torch.bfloat16)
-        b1["proprio"] = b1["proprio"].to(dev, torch.bfloat16).reshape(1, -1)
-
-        def infer_once():
-            out = eng.forward(b1["input_ids"], b1["attention_mask"], b1["pixel_values"], b1["labels"], proprio=b1["proprio"], train=False)
-            ah, _ = eng.gather_action_hidden(out["hidden"], out["action_rows"])
-            return eng.head.fwd(ah)[0]
-
-        for _ in range(3):
-            infer_once()
-        torch.cuda.synchronize()
-        ti = time.perf_counter()
-        n_inf = 20
-        for _ in range(n_inf):
-            pred1 = infer_once()
-        torch.cuda.synchronize()
-        ms_inf = 1e3 * (time.perf_counter() - ti) / n_inf
-        infer = {"workload": "BASELINE.json configs[1]: OpenVLA-7B L1-regression inference, 2x224x224 images + proprio, bf16, batch 1 (one 8x7 action chunk per forward)",
-                 "ms_per_chunk": ms_inf, "chunks_per_s": 1e3 / ms_inf, "actions_per_s": 1e3 / ms_inf * cfg.chunk}
-
     roofline = cpu = None
     # dominant kernel (gemm_nt) timed launch by launch with HIP events on the launch stream over one more step.  EVERY rank
     # runs the step (it contains the gradient collectives); only rank 0 records events.
@@ -334,6 +311,48 @@ def main():
         roofline["step_mfma_frac"] = (train_f * args.batch / (ms_per_step * 1e-3)) / 1e12 / PEAK_BF16_TFLOPS
         if not args.no_cpu_baseline and not args.tiny:
             cpu = cpu_baseline(cfg, S, train_f)
+    # ---- BASELINE.json configs[1]: single-chunk inference, batch 1; rank 0 only, no collectives.  Runs LAST on the training
+    # engine: (1) adapters applied on the fly (the state during fine-tuning evaluation), (2) adapters merged into the base
+    # weights as the reference deploys them (merge_lora_weights_and_save.py), (3) the merged forward replayed from a hipGraph.
+    infer = None
+    if rank == 0 and not args.no_inference:
+        b1 = synth.make_batch(1, seed=77, num_images=cfg.num_images, chunk=cfg.chunk, action_dim=cfg.action_dim, proprio_dim=cfg.proprio_dim)
+        b1["pixel_values"] = b1["pixel_values"].to(dev, torch.bfloat16)
+        b1["proprio"] = b1["proprio"].to(dev, torch.bfloat16).reshape(1, -1)
+
+        def infer_once():
+            out = eng.forward(b1["input_ids"], b1["attention_mask"], b1["pixel_values"], b1["labels"], proprio=b1["proprio"], train=False)
+            ah, _ = eng.gather_action_hidden(out["hidden"], out["action_rows"])
+            return eng.head.fwd(ah)[0]
+
+        def time_it(fn, n=20):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            ti = time.perf_counter()
+            for _ in range(n):
+                r = fn()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - ti) / n, r
+
+        ms_lora, _ = time_it(infer_once)
+        eng.merge_lora()
+        ms_merged, pred_e = time_it(infer_once)
+        graph = engine_mod.ChunkGraph(eng, 1, b1["input_ids"].shape[1], b1["pixel_values"].shape, head=eng.head, use_proprio=True)
+        graph.load(b1["input_ids"], b1["attention_mask"], b1["pixel_values"], b1["labels"], b1["proprio"])
+        graph.capture()
+
+        def graph_once():   # what a deployment does per observation: refresh the static inputs, replay, read the actions back
+            graph.load(b1["input_ids"], b1["attention_mask"], b1["pixel_values"], b1["labels"], b1["proprio"])
+            return graph.replay()[0]
+
+        ms_graph, pred_g = time_it(graph_once, n=50)
+        assert torch.equal(pred_g, pred_e), "hipGraph replay must reproduce the eager actions bit for bit"
+        infer = {"workload": "BASELINE.json configs[1]: OpenVLA-7B L1-regression inference, 2x224x224 images + proprio, bf16, batch 1 (one 8x7 action chunk per forward)",
+                 "ms_per_chunk": ms_graph, "chunks_per_s": 1e3 / ms_graph, "actions_per_s": 1e3 / ms_graph * cfg.chunk,
+                 "mode": "LoRA merged (W += 0.5 B A on device) + hipGraph replay",
+                 "ms_per_chunk_merged_eager": ms_merged, "ms_per_chunk_unmerged_eager": ms_lora}
+
     if world > 1:
         dist.barrier()
     if rank == 0:

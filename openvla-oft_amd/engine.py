@@ -167,10 +167,26 @@ class LoraLinear:
                 out[rn + ".lora_B.weight"] = Bm[g * self.group_n:(g + 1) * self.group_n]
         return out
 
+    def merge(self):
+        """W += s * B A in place (peft `merge_and_unload`, vla-scripts/merge_lora_weights_and_save.py:60-67): per fused group
+        one rank-r GEMM whose epilogue adds the frozen weight (delta and sum each rounded to bf16, as peft's
+        `weight.data += delta` on bf16 tensors).  The adapters stay allocated but are no longer applied: inference only."""
+        if not self.has_lora or getattr(self, "merged", False):
+            return
+        if self.AT is None:
+            self.refresh_derived()
+        gn, r = self.group_n, self.r
+        for g in range(self.groups):
+            Wg = self.W[g * gn:(g + 1) * gn]
+            ops.gemm(self.B.data[g * gn:(g + 1) * gn], self.AT[:, g * r:(g + 1) * r], out=Wg, residual=Wg, alpha=self.scale)
+        if self.WT is not None:
+            ops.transpose(self.W, self.WT)
+        self.merged = True
+
     def fwd(self, x, *, act=0, residual=None, colscale=None, c_pre=None, film=None, out=None):
         """x [M, in] -> (y [M, out], saved)."""
         t_s = None
-        if self.has_lora:
+        if self.has_lora and not getattr(self, "merged", False):
             t_s = ops.gemm(x, self.A.data, alpha=self.scale)
             y = ops.gemm(x, self.W, out=out, bias=self.bias, act=act, residual=residual, colscale=colscale, c_pre=c_pre, film=film,
                          a2=t_s, b2=self.B.data, k2_group_n=self.group_n if self.groups > 1 else 0)
@@ -182,6 +198,8 @@ class LoraLinear:
         """dy [M, out] (gradient w.r.t. the pre-activation linear output) -> dx [M, in]; accumulates LoRA grads."""
         x, t_s = saved
         dx = None
+        if getattr(self, "merged", False):
+            raise RuntimeError(f"{self.name}: LoRA adapters were merged into the base weight; this engine is inference-only")
         if self.has_lora:
             r, G, gn = self.r, self.groups, self.group_n
             # dt[:, g] = s * dy_g . B_g for every fused group in ONE block-diagonal skinny GEMM
@@ -647,6 +665,28 @@ class VLAEngine:
                 yield from m.linears()
         yield from self.llm.linears()
 
+    def merge_lora(self):
+        """Folds every LoRA adapter of the VLM into its base weight (what the reference does before deployment:
+        merge_lora_weights_and_save.py).  Afterwards forward() runs plain GEMMs; training entry points raise."""
+        for lin in self.vlm_linears():
+            if isinstance(lin, LoraLinear):
+                lin.merge()
+        self.lora_merged = True
+
+    def merged_state_dict(self) -> Dict[str, torch.Tensor]:
+        """Base VLM weights under the reference's HF key layout (un-fused q/k/v, gate/up), after merge_lora(): what
+        merge_lora_weights_and_save.py writes with `save_pretrained`."""
+        out: Dict[str, torch.Tensor] = {}
+        for lin in self.vlm_linears():
+            if not isinstance(lin, LoraLinear):
+                continue
+            gn = lin.group_n
+            for g, rn in enumerate(lin.ref_names):
+                out[rn + ".weight"] = lin.W[g * gn:(g + 1) * gn]
+                if lin.bias is not None:
+                    out[rn + ".bias"] = lin.bias[g * gn:(g + 1) * gn]
+        return out
+
     def vlm_linears(self):
         yield from self.dino.linears()
         yield from self.siglip.linears()
@@ -784,22 +824,41 @@ class VLAEngine:
         Returns dict(hidden [B,S,D], P, action_rows [B,A], patches, saved).  `cached_patches` (the `patches` of a previous
         call) skips the vision towers / projector / proprio projector: the DDIM sampler reuses them across its steps
         (modeling_prismatic.py:810)."""
-        cfg = self.cfg
         dev = self.device
         B, L = input_ids.shape
         ids = input_ids.to(dev, torch.int64).contiguous()
         lab = labels.to(dev, torch.int64).contiguous()
+        lens = self.check_right_padding(attention_mask)
+        film_avg = None
+        if self.use_film and cached_patches is None:
+            film_avg = self.language_average(ids, labels.to("cpu"))
+        return self.forward_dev(ids, lab, lens.to(torch.int32).to(dev), pixel_values, proprio=proprio, noisy_actions=noisy_actions,
+                                timestep_emb=timestep_emb, train=train, proprio_projector=proprio_projector,
+                                noisy_action_projector=noisy_action_projector, cached_patches=cached_patches, film_avg=film_avg)
+
+    @staticmethod
+    def check_right_padding(attention_mask) -> torch.Tensor:
+        """Host-side validation of the collator's mask; returns the per-row text lengths (int64, CPU)."""
         am = attention_mask.to("cpu").bool()
+        L = am.shape[1]
         lens = am.sum(1)
         if not bool((am == (torch.arange(L)[None, :] < lens[:, None])).all()):
             raise ValueError("attention_mask must be right padding (a prefix of ones per row), as produced by the reference collator")
+        return lens
+
+    def forward_dev(self, ids, lab, text_lens, pixel_values, proprio=None, noisy_actions=None, timestep_emb=None, train=False,
+                    proprio_projector=None, noisy_action_projector=None, cached_patches=None, film_avg=None):
+        """Device-only part of forward(): ids / lab int64 [B, L] and text_lens int32 [B] already on the device; launches
+        kernels and allocates, never synchronises or reads host memory -- the part a hipGraph can capture (ChunkGraph)."""
+        cfg = self.cfg
+        dev = self.device
+        B, L = ids.shape
         proprio_projector = proprio_projector if proprio_projector is not None else self.proprio
         noisy_action_projector = noisy_action_projector if noisy_action_projector is not None else self.noisy
         vsaved = psaved = nsaved = None
         if cached_patches is not None:
             base, n_vis = cached_patches
         else:
-            film_avg = self.language_average(ids, labels.to("cpu")) if self.use_film else None
             patches, vsaved = self.vision_fwd(pixel_values.to(dev, BF16).contiguous(), train, film_avg)
             n_vis = patches.shape[1]
             base = patches
@@ -826,7 +885,7 @@ class VLAEngine:
             noisy_feats = nf[: B * A].view(B, A, cfg.llm_dim)
         mm, action_rows = ops.assemble_multimodal(ids, lab, self.embed, allp.contiguous(), A=A, noisy=noisy_feats, action_dim=cfg.action_dim)
         S = P + L
-        kv_len = (lens + P).to(torch.int32).to(dev)
+        kv_len = (text_lens + P).to(torch.int32)
         hidden, lsaved = self.llm.fwd(mm.view(B * S, cfg.llm_dim), B, S, kv_len, train)
         saved = (vsaved, psaved, nsaved, lsaved, B, S, P, n_vis, proprio_projector, noisy_action_projector, action_rows) if train else None
         return dict(hidden=hidden.view(B, S, cfg.llm_dim), P=P, action_rows=action_rows, patches=(base, n_vis), saved=saved)
@@ -901,3 +960,73 @@ class VLAEngine:
         ops.gather_rows(dah, idx, D, dst=dhidden, scatter_add=True)
         self.backward_from_hidden(dhidden, out["saved"])
         return loss_sum, pred.numel(), pred
+
+
+# ======================================================================================================================
+# hipGraph replay of the single-chunk inference forward (BASELINE.json configs[1])
+# ======================================================================================================================
+class ChunkGraph:
+    """The batch-B inference forward (vision towers on their two streams -> projector -> assembly -> Llama stack -> action
+    row gather -> optional L1 head) captured ONCE as a hipGraph and replayed per observation: ~1.3 k kernel launches become
+    one graph launch, which is what bounds batch-1 latency.  Inputs are copied into static device buffers before each
+    replay; outputs are static buffers too (clone them to keep a result across calls).
+
+    Everything the capture allocates (activations, split-K workspaces) lives in the graph's private pool and stays valid as
+    long as this object does.  Text length L is part of the captured shapes: callers pad the prompt to a bucket (right
+    padding is masked exactly: padded keys contribute exact zeros) or keep one ChunkGraph per L."""
+
+    def __init__(self, engine: "VLAEngine", B: int, L: int, pixel_shape, *, head=None, use_proprio: bool = True, proprio_projector=None):
+        if engine.use_film:
+            raise NotImplementedError("ChunkGraph: the FiLM language average is computed host-side; use the eager forward")
+        dev = engine.device
+        self.engine, self.head, self.B, self.L = engine, head, B, L
+        self.proprio_projector = proprio_projector
+        self.ids = torch.zeros((B, L), dtype=torch.int64, device=dev)
+        self.lab = torch.full((B, L), -100, dtype=torch.int64, device=dev)
+        self.lens = torch.full((B,), L, dtype=torch.int32, device=dev)
+        self.pixels = torch.zeros(tuple(pixel_shape), dtype=BF16, device=dev)
+        self.proprio = torch.zeros((B, engine.cfg.proprio_dim), dtype=BF16, device=dev) if use_proprio else None
+        self.graph = None
+        self.out = None
+
+    def _run(self):
+        eng = self.engine
+        out = eng.forward_dev(self.ids, self.lab, self.lens, self.pixels, proprio=self.proprio, train=False,
+                              proprio_projector=self.proprio_projector)
+        ah, _ = eng.gather_action_hidden(out["hidden"], out["action_rows"])
+        pred = self.head.fwd(ah)[0] if self.head is not None else None
+        return pred, ah
+
+    def load(self, input_ids, attention_mask, pixel_values, labels, proprio=None):
+        lens = VLAEngine.check_right_padding(attention_mask)
+        assert tuple(input_ids.shape) == (self.B, self.L), f"ChunkGraph captured for ids {(self.B, self.L)}, got {tuple(input_ids.shape)}"
+        self.ids.copy_(input_ids.to(torch.int64), non_blocking=True)
+        self.lab.copy_(labels.to(torch.int64), non_blocking=True)
+        self.lens.copy_(lens.to(torch.int32), non_blocking=True)
+        self.pixels.copy_(pixel_values.reshape(self.pixels.shape), non_blocking=True)
+        if self.proprio is not None:
+            self.proprio.copy_(proprio.reshape(self.proprio.shape), non_blocking=True)
+
+    def capture(self):
+        """Call after load() of a representative input: one eager warm-up (lazy tables, kernel attributes), then the capture."""
+        assert ops.PROFILE is None, "no per-launch event timing inside a graph capture"
+        self._run()
+        torch.cuda.synchronize(self.engine.device)
+        outer_ws, ops._ws_cache = ops._ws_cache, {}          # workspaces allocated while capturing belong to the graph's pool
+        try:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = self._run()
+        finally:
+            self._ws, ops._ws_cache = ops._ws_cache, outer_ws
+        return self
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+    def __call__(self, input_ids, attention_mask, pixel_values, labels, proprio=None):
+        self.load(input_ids, attention_mask, pixel_values, labels, proprio)
+        if self.graph is None:
+            self.capture()
+        return self.replay()

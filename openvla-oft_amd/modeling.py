@@ -14,6 +14,8 @@ import math
 from dataclasses import dataclass
 from typing import Any, Dict, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -21,7 +23,7 @@ import torch.nn as nn
 from . import ops
 from .config import VLAConfig
 from .diffusion import DDIMScheduler, SinusoidalPositionalEncoding
-from .engine import ActionHead, MlpProjector, ParamStore, VLAEngine, build_component
+from .engine import ChunkGraph, ActionHead, MlpProjector, ParamStore, VLAEngine, build_component
 from .weights import make_getter
 
 BF16 = torch.bfloat16
@@ -314,6 +316,23 @@ class OpenVLAForActionPrediction(_StoreModule):
         self.config = type("Cfg", (), {"image_sizes": [cfg.dino.image_size, cfg.siglip.image_size], "pad_token_id": cfg.pad_token_id})()
         self.training = False
         self._anchor = torch.zeros((), device=self.device, requires_grad=True)
+        # hipGraph replay of predict_action (L1 / discrete paths).  Off by default: a captured graph pins the parameter
+        # buffers it was captured with, so it is for deployment (weights frozen), not for evaluation inside a training loop.
+        self.use_graph = os.environ.get("OVLA_INFER_GRAPH", "0") == "1"
+        self._graphs: Dict[tuple, ChunkGraph] = {}
+
+    def merge_and_unload(self):
+        """peft `merge_and_unload()` of merge_lora_weights_and_save.py:60-67 on device: W += (alpha/r) B A for every adapted
+        Linear; the model becomes inference-only.  Returns self, like peft."""
+        self.engine.merge_lora()
+        self._graphs.clear()
+        return self
+
+    def enable_graph_replay(self, on: bool = True):
+        self.use_graph = on
+        if not on:
+            self._graphs.clear()
+        return self
 
     # -- forward (:499-675) -------------------------------------------------------------------------------------------
     def __call__(self, *a, **k):
@@ -405,10 +424,27 @@ class OpenVLAForActionPrediction(_StoreModule):
                 cur = sched.step(eps, int(t), cur).prev_sample.to(BF16).float()
             normalized = cur.reshape(cfg.chunk, cfg.action_dim).numpy()
             return self._unnormalize_actions(normalized, unnorm_key), ah.view(1, A, cfg.llm_dim)
-        out = self.engine.forward(ids, mask, pixel_values, labels, proprio=prop, train=False,
-                                  proprio_projector=proprio_projector.comp if use_proprio else None)
-        ah, _ = self.engine.gather_action_hidden(out["hidden"], out["action_rows"])       # rows P+NPT .. P+NPT+A-1 (:915-920)
-        actions_hidden_states = ah.view(1, A, cfg.llm_dim)
+        if self.use_graph and not self.engine.use_film:
+            # one hipGraph per (text length, head, projector): ~1.3 k launches -> one graph launch (engine.ChunkGraph)
+            head_comp = getattr(action_head, "comp", None) if action_head is not None else None
+            pp_comp = proprio_projector.comp if use_proprio else None
+            key = (ids.shape[1], tuple(pixel_values.shape), id(head_comp), id(pp_comp))
+            g = self._graphs.get(key)
+            if g is None:
+                g = self._graphs[key] = ChunkGraph(self.engine, 1, ids.shape[1], pixel_values.shape, head=head_comp, use_proprio=use_proprio,
+                                                   proprio_projector=pp_comp)
+                g._keep = (head_comp, pp_comp)   # the captured kernels read these parameter buffers: keep them alive
+            pred, ah = g(ids, mask, pixel_values, labels, prop)
+            actions_hidden_states = ah.view(1, A, cfg.llm_dim).clone()
+            if action_head is not None:
+                normalized = pred.reshape(cfg.chunk, cfg.action_dim).float().cpu().numpy()
+                return self._unnormalize_actions(normalized, unnorm_key), actions_hidden_states
+            ah = actions_hidden_states.view(A, cfg.llm_dim)
+        else:
+            out = self.engine.forward(ids, mask, pixel_values, labels, proprio=prop, train=False,
+                                      proprio_projector=proprio_projector.comp if use_proprio else None)
+            ah, _ = self.engine.gather_action_hidden(out["hidden"], out["action_rows"])   # rows P+NPT .. P+NPT+A-1 (:915-920)
+            actions_hidden_states = ah.view(1, A, cfg.llm_dim)
         if action_head is not None:                                                       # :923-927
             normalized = action_head.predict_action(actions_hidden_states).reshape(cfg.chunk, cfg.action_dim).float().cpu().numpy()
         else:                                                                             # :929-942

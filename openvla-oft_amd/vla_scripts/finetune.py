@@ -29,7 +29,7 @@ from ..dp import GradReducer
 from ..engine import VLAEngine
 from ..prismatic.training.train_utils import get_current_action_mask, get_next_actions_mask
 from ..prismatic.vla import constants as C
-from ..weights import make_getter, random_state_dict
+from ..weights import make_getter, random_state_dict, save_lora_adapter
 
 
 @dataclass
@@ -155,9 +155,7 @@ def save_training_checkpoint(run_dir: Path, log_step: int, engine: VLAEngine, da
         if dataset_statistics is not None:
             (ckpt / "dataset_statistics.json").write_text(json.dumps(dataset_statistics))
         exp = {k: v.detach().to("cpu") for k, v in engine.export_trainable("data").items()}
-        from safetensors.torch import save_file
-
-        save_file({k: v.contiguous() for k, v in exp.items() if ".lora_" in k}, str(ckpt / "lora_adapter" / "adapter_model.safetensors"))
+        save_lora_adapter(ckpt / "lora_adapter", exp, r=engine.cfg.lora_rank, lora_alpha=engine.cfg.lora_alpha)   # peft on-disk format
         groups = {"proprio_projector": "proprio_projector.", "noisy_action_projector": "noisy_action_projector.", "action_head": "action_head.",
                   "vision_backbone": "vision_backbone."}   # FiLM scale/shift Linears (finetune.py:640-645 saves the wrapped backbone)
         for comp, prefix in groups.items():

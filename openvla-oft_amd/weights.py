@@ -105,3 +105,56 @@ def random_state_dict(cfg: VLAConfig, device, seed: int = 0, *, lora: bool = Tru
         lin("noisy_action_projector.fc1", D, 1, with_lora=False, s=0.5)
         lin("noisy_action_projector.fc2", D, D, with_lora=False, s=0.02)
     return sd
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# peft LoRA adapter directory (`lora_adapter/`: finetune.py:617-619 `vla.module.save_pretrained(adapter_dir)`, read back by
+# `PeftModel.from_pretrained` in merge_lora_weights_and_save.py:58-60).  peft 0.11.1 (pyproject.toml) is absent from this
+# image; the layout below is its published on-disk format: `adapter_config.json` + `adapter_model.safetensors` whose keys
+# are `base_model.model.<module path>.lora_{A,B}.weight` (the adapter name "default" is dropped when saving).
+# ----------------------------------------------------------------------------------------------------------------------
+PEFT_PREFIX = "base_model.model."
+
+
+def save_lora_adapter(adapter_dir, tensors: Dict[str, torch.Tensor], *, r: int, lora_alpha: int, base_model_name_or_path: str = "openvla/openvla-7b"):
+    """`tensors`: {<module path>.lora_A.weight | .lora_B.weight: tensor} (engine.export_trainable naming)."""
+    import json
+    from pathlib import Path
+
+    from safetensors.torch import save_file
+
+    d = Path(adapter_dir)
+    d.mkdir(parents=True, exist_ok=True)
+    lora = {PEFT_PREFIX + k: v.detach().to("cpu").contiguous() for k, v in tensors.items() if ".lora_A." in k or ".lora_B." in k}
+    save_file(lora, str(d / "adapter_model.safetensors"))
+    cfg = {"peft_type": "LORA", "task_type": None, "base_model_name_or_path": base_model_name_or_path, "r": r, "lora_alpha": lora_alpha,
+           "lora_dropout": 0.0, "bias": "none", "target_modules": "all-linear", "init_lora_weights": "gaussian", "fan_in_fan_out": False,
+           "inference_mode": True, "modules_to_save": None, "use_rslora": False, "use_dora": False}
+    (d / "adapter_config.json").write_text(json.dumps(cfg, indent=2, sort_keys=True))
+    return d
+
+
+def load_lora_adapter(adapter_dir) -> tuple[Dict[str, torch.Tensor], dict]:
+    """-> ({<module path>.lora_A.weight: tensor, ...}, adapter_config).  Accepts keys with or without peft's
+    `base_model.model.` prefix and with an explicit `.default` adapter name."""
+    import json
+    from pathlib import Path
+
+    from safetensors.torch import load_file
+
+    d = Path(adapter_dir)
+    f = d / "adapter_model.safetensors"
+    if not f.is_file():
+        raise ValueError(f"no adapter_model.safetensors in {d} (peft .bin adapters are pickles and are not loaded)")
+    cfg = json.loads((d / "adapter_config.json").read_text()) if (d / "adapter_config.json").is_file() else {}
+    if cfg and cfg.get("peft_type", "LORA") != "LORA":
+        raise ValueError(f"unsupported peft_type {cfg.get('peft_type')!r}")
+    if cfg.get("use_rslora") or cfg.get("use_dora"):
+        raise ValueError("rsLoRA / DoRA adapters are not produced by the reference (finetune.py:862-871) and are not supported")
+    out = {}
+    for k, v in load_file(str(f)).items():
+        if k.startswith(PEFT_PREFIX):
+            k = k[len(PEFT_PREFIX):]
+        k = k.replace(".lora_A.default.", ".lora_A.").replace(".lora_B.default.", ".lora_B.")
+        out[k] = v
+    return out, cfg

@@ -102,3 +102,51 @@ def test_product_never_imports_the_oracle():
         if "import oracle" in txt or "from oracle" in txt:
             offenders.append(str(f))
     assert not offenders, offenders
+
+
+def test_peft_adapter_directory_roundtrip(tmp_path):
+    """lora_adapter/ in peft's on-disk format (finetune.py:617-619 writes it with save_pretrained; merge_lora_weights_and_save.py
+    reads it back with PeftModel.from_pretrained).  peft itself is absent: parity of the layout is unpinned, restated from
+    its published format (adapter_config.json + adapter_model.safetensors, `base_model.model.` key prefix)."""
+    import json
+
+    from safetensors.torch import load_file, save_file
+
+    w = importlib.import_module("openvla-oft_amd.weights")
+    t = {"language_model.model.layers.0.self_attn.q_proj.lora_A.weight": torch.randn(4, 16).to(torch.bfloat16),
+         "language_model.model.layers.0.self_attn.q_proj.lora_B.weight": torch.randn(16, 4).to(torch.bfloat16),
+         "action_head.model.fc1.weight": torch.randn(3, 3)}
+    d = w.save_lora_adapter(tmp_path / "lora_adapter", t, r=4, lora_alpha=2)
+    raw = load_file(str(d / "adapter_model.safetensors"))
+    assert set(raw) == {"base_model.model." + k for k in t if ".lora_" in k}, "only adapter tensors, peft key prefix"
+    cfg = json.loads((d / "adapter_config.json").read_text())
+    assert cfg["peft_type"] == "LORA" and cfg["r"] == 4 and cfg["lora_alpha"] == 2 and cfg["target_modules"] == "all-linear"
+    back, cfg2 = w.load_lora_adapter(d)
+    assert cfg2 == cfg and set(back) == {k for k in t if ".lora_" in k}
+    assert all(torch.equal(back[k], t[k]) for k in back)
+    # adapters saved with an explicit adapter name and without the prefix are accepted too
+    save_file({"x.lora_A.default.weight": torch.zeros(2, 2), "base_model.model.x.lora_B.default.weight": torch.zeros(2, 2)},
+              str(d / "adapter_model.safetensors"))
+    back, _ = w.load_lora_adapter(d)
+    assert set(back) == {"x.lora_A.weight", "x.lora_B.weight"}
+    (d / "adapter_config.json").write_text(json.dumps({**cfg, "use_dora": True}))
+    with pytest.raises(ValueError, match="DoRA"):
+        w.load_lora_adapter(d)
+
+
+def test_save_sharded_layout(tmp_path):
+    m = importlib.import_module("openvla-oft_amd.vla_scripts.merge_lora_weights_and_save")
+    import json
+
+    from safetensors.torch import load_file
+
+    sd = {f"w{i}": torch.full((256,), float(i)) for i in range(5)}     # 1 KiB each
+    files = m.save_sharded(sd, tmp_path / "a", max_shard_bytes=2048)
+    assert [f.name for f in files] == ["model-00001-of-00003.safetensors", "model-00002-of-00003.safetensors", "model-00003-of-00003.safetensors"]
+    idx = json.loads((tmp_path / "a" / "model.safetensors.index.json").read_text())
+    assert idx["metadata"]["total_size"] == 5 * 1024 and idx["weight_map"]["w4"] == "model-00003-of-00003.safetensors"
+    got = {}
+    for f in files:
+        got.update(load_file(str(f)))
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+    assert [f.name for f in m.save_sharded(sd, tmp_path / "b")] == ["model.safetensors"]
