@@ -183,9 +183,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     split = bid / tiles_mn;
     t_mn = bid - split * tiles_mn;
   } else {
-    rem_unit = bid - p.full_tiles;
-    t_mn = p.full_tiles + rem_unit / p.rem_splits;
-    split = rem_unit % p.rem_splits;
+    // remainder units, split-major and XCD-banded like the full tiles: the workgroups an XCD runs together are the SAME
+    // K part of neighbouring tiles, so they share A / B panels through that XCD's L2 (tile-major order put the K parts of
+    // one tile on 8 different XCDs: nothing shared).  Slab index stays (tile, split) for the reduce kernel.
+    int u = bid - p.full_tiles;
+    const int nrem = p.rem_tiles * p.rem_splits;
+    const int xcd = u & 7, q = nrem >> 3, r = nrem & 7;
+    u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (u >> 3);
+    split = u / p.rem_tiles;
+    const int rt = u - split * p.rem_tiles;
+    t_mn = p.full_tiles + rt;
+    rem_unit = rt * p.rem_splits + split;
   }
   constexpr int GROUP = 8;
   const int group_sz = GROUP * p.tiles_n;
