@@ -1,0 +1,155 @@
+"""Parity at BASELINE.json's FULL sizes: two Llama-2-7B-sized decoder layers (D 4096, 32 heads x 128, MLP 11008, LoRA r 32)
+on the bench's own GEMM M (8 x 608 = 4864 rows, ragged key padding), forward and backward, through the same HIP kernels and
+tile schedules the benchmark runs (256x256 hybrid tiles, K-extension, split-K skinny GEMMs, 8-wave attention).
+
+The checker is the oracle's decoder (`oracle.vla_oracle.Oracle.llm`) evaluated ON THE GPU with stock torch ops in fp32 and
+in its bf16-emulation mode; the CPU would need minutes per layer at this size.  Criterion as in test_engine_gpu.py: the
+HIP path must be as close to fp32 as the bf16 emulation is (x2 slack), and tight against the emulation itself."""
+import dataclasses
+import importlib
+
+import pytest
+import torch
+
+from oracle import vla_oracle as vo
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def rel2(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+def test_two_full_size_llama_layers_forward_backward(dev):
+    load = importlib.import_module
+    engine_mod, config_mod = load("openvla-oft_amd.engine"), load("openvla-oft_amd.config")
+    cfg = dataclasses.replace(config_mod.OPENVLA_7B, llm_layers=2)
+    ocfg = dataclasses.replace(vo.OracleConfig(), llm_layers=2)
+    assert (ocfg.llm_dim, ocfg.llm_heads, ocfg.llm_ff) == (cfg.llm_dim, cfg.llm_heads, cfg.llm_ff) == (4096, 32, 11008)
+    B, S, D, r = 8, 608, cfg.llm_dim, cfg.lora_rank
+    g = torch.Generator(device=dev).manual_seed(0)
+
+    def rn(*shape, s=1.0):
+        return (torch.randn(*shape, generator=g, device=dev) * s).to(BF)
+
+    sd = {"language_model.model.norm.weight": (1 + 0.1 * torch.randn(D, generator=g, device=dev)).to(BF)}
+    for i in range(2):
+        p = f"language_model.model.layers.{i}."
+        for name, o, k in (("self_attn.q_proj", D, D), ("self_attn.k_proj", D, D), ("self_attn.v_proj", D, D), ("self_attn.o_proj", D, D),
+                           ("mlp.gate_proj", cfg.llm_ff, D), ("mlp.up_proj", cfg.llm_ff, D), ("mlp.down_proj", D, cfg.llm_ff)):
+            sd[p + name + ".weight"] = rn(o, k, s=0.02)
+            sd[p + name + ".lora_A.weight"] = rn(r, k, s=1.0 / r)
+            sd[p + name + ".lora_B.weight"] = rn(o, r, s=0.02)
+        sd[p + "input_layernorm.weight"] = (1 + 0.1 * torch.randn(D, generator=g, device=dev)).to(BF)
+        sd[p + "post_attention_layernorm.weight"] = (1 + 0.1 * torch.randn(D, generator=g, device=dev)).to(BF)
+    x = rn(B, S, D, s=0.5)
+    dout = rn(B * S, D, s=0.05)
+    lens = torch.tensor([608, 600, 608, 577, 608, 590, 608, 608], dtype=torch.int32, device=dev)
+    mask = torch.arange(S, device=dev)[None, :] < lens[:, None]
+
+    # ---- HIP path ----
+    store = engine_mod.ParamStore(dev)
+    llm = engine_mod.LlamaStack(store, cfg, lambda n: sd[n], lora=True)
+    store.finalize()
+    for lin in llm.linears():
+        lin.refresh_derived()
+    valid = mask.reshape(-1)
+    store.zero_grad()
+    hid, saved = llm.fwd(x.view(B * S, D).clone(), B, S, lens, train=True)
+    # rows past kv_len are don't-care on both sides: no gradient enters through them
+    dx = llm.bwd((dout.float() * valid[:, None]).to(BF), saved)
+    torch.cuda.synchronize()
+    names = {}
+    for lin in llm.linears():
+        names.update(lin.export("grad"))
+
+    # ---- oracle decoder on the GPU: fp32 and bf16 emulation, gradients by autograd ----
+    def run(mode):
+        sdg = {k: (v.float().requires_grad_(True) if ".lora_" in k else v.float()) for k, v in sd.items()}
+        xin = x.float().clone().requires_grad_(True)
+        h = vo.Oracle(ocfg, sdg, mode=mode).llm(xin, mask)
+        h.backward(dout.float().view(B, S, D) * mask[:, :, None])      # rows past kv_len are don't-care on both sides
+        return h.detach(), xin.grad.detach(), {k: v.grad for k, v in sdg.items() if ".lora_" in k}
+
+    h32, dx32, g32 = run("fp32")
+    h16, dx16, g16 = run("bf16")
+    hv = hid.float()[valid]
+    e_emu, e16, e32 = rel(h16.view(-1, D)[valid], h32.view(-1, D)[valid]), rel(hv, h16.view(-1, D)[valid]), rel(hv, h32.view(-1, D)[valid])
+    print(f"hidden (4864 x 4096): hip vs emu {e16:.3e}  hip vs fp32 {e32:.3e}  emu vs fp32 {e_emu:.3e}")
+    assert e16 < 2e-2 and e32 < max(2 * e_emu, 2e-2)
+
+    d_emu, d16, d32 = rel2(dx16.view(-1, D)[valid], dx32.view(-1, D)[valid]), rel2(dx.float()[valid], dx16.view(-1, D)[valid]), rel2(dx.float()[valid], dx32.view(-1, D)[valid])
+    print(f"d inputs_embeds rel-L2: hip vs emu {d16:.3e}  hip vs fp32 {d32:.3e}  emu vs fp32 {d_emu:.3e}")
+    assert d32 < max(2 * d_emu, 2e-2)
+    worst = 0.0
+    for k, gh in names.items():
+        e_h, e_e = rel2(gh, g32[k]), rel2(g16[k], g32[k])
+        worst = max(worst, e_h / max(e_e, 1e-3))
+        assert e_h < max(2 * e_e, 2e-2), f"{k}: hip {e_h:.3e} vs emulation {e_e:.3e}"
+    print(f"{len(names)} LoRA gradients: worst (hip error / emulation error) = {worst:.2f}")
+
+
+@pytest.mark.parametrize("which", ["dino", "siglip"])
+def test_full_size_vit_tower_blocks_forward_backward(dev, which):
+    """The two vision towers at their real widths (DINOv2 ViT-L/14 reg4: 1024 / 16 heads x 64 / MLP 4096 / LayerScale / 5 prefix
+    tokens; SigLIP so400m: 1152 / 16 heads x 72 / MLP 4304 / tanh-free GELU), 8 samples x 2 images of 224 x 224, cut to depth 3
+    (blocks 0 and 1 execute: `get_intermediate_layers(n={depth-2})`), LoRA on every Linear."""
+    load = importlib.import_module
+    engine_mod, config_mod = load("openvla-oft_amd.engine"), load("openvla-oft_amd.config")
+    full = vo.OracleConfig()
+    ocfg = dataclasses.replace(full, llm_layers=0, llm_dim=64, llm_ff=64, vocab=64, dino=dataclasses.replace(full.dino, depth=3),
+                               siglip=dataclasses.replace(full.siglip, depth=3))
+    sd_cpu = vo.random_state_dict(ocfg, seed=4)
+    prefix = "vision_backbone.featurizer." if which == "dino" else "vision_backbone.fused_featurizer."
+    ovc = ocfg.dino if which == "dino" else ocfg.siglip
+    sd = {k: v.to(dev).to(BF) for k, v in sd_cpu.items() if k.startswith(prefix)}
+    cfg = config_mod.VLAConfig.from_any(ocfg)
+    vc = cfg.dino if which == "dino" else cfg.siglip
+    B, I = 8, 2
+    g = torch.Generator(device=dev).manual_seed(1)
+    pixels = torch.randn(B, 6 * I, 224, 224, generator=g, device=dev).to(BF)
+    c0 = 0 if which == "dino" else 3
+    T = vc.n_patches + vc.n_prefix
+
+    store = engine_mod.ParamStore(dev)
+    tower = engine_mod.VitTower(store, prefix, vc, lambda n: sd[n], cfg, lora=True)
+    store.finalize()
+    for lin in tower.linears():
+        lin.refresh_derived()
+    store.zero_grad()
+    tok, saved = tower.fwd(pixels, c0, I, train=True)
+    dtok = (torch.randn(B * I * T, vc.dim, generator=g, device=dev) * 0.05).to(BF)
+    dtok.view(B * I, T, vc.dim)[:, : vc.n_prefix] = 0          # prefix tokens are dropped by the backbone: no gradient
+    tower.bwd(dtok.clone(), saved)
+    torch.cuda.synchronize()
+    grads = {}
+    for lin in tower.linears():
+        grads.update(lin.export("grad"))
+
+    imgs = torch.cat([pixels[:, 6 * i + c0: 6 * i + c0 + 3] for i in range(I)], 0).view(I, B, 3, 224, 224).transpose(0, 1).reshape(B * I, 3, 224, 224)
+
+    def run(mode):
+        sdg = {k: (v.float().requires_grad_(True) if ".lora_" in k else v.float()) for k, v in sd.items()}
+        out = vo.Oracle(ocfg, sdg, mode=mode).vit(imgs.float(), prefix, ovc)
+        out.backward(dtok.float().view(B * I, T, vc.dim)[:, vc.n_prefix:])
+        return out.detach(), {k: v.grad for k, v in sdg.items() if ".lora_" in k}
+
+    o32, g32 = run("fp32")
+    o16, g16 = run("bf16")
+    hip = tok.float().view(B * I, T, vc.dim)[:, vc.n_prefix:]
+    e_emu, e16, e32 = rel(o16, o32), rel(hip, o16), rel(hip, o32)
+    print(f"{which} tokens: hip vs emu {e16:.3e}  hip vs fp32 {e32:.3e}  emu vs fp32 {e_emu:.3e}")
+    assert e16 < 2e-2 and e32 < max(2 * e_emu, 2e-2)
+    worst = 0.0
+    for k, gh in grads.items():
+        e_h, e_e = rel2(gh, g32[k]), rel2(g16[k], g32[k])
+        worst = max(worst, e_h / max(e_e, 1e-3))
+        assert e_h < max(2 * e_e, 2e-2), f"{k}: hip {e_h:.3e} vs emulation {e_e:.3e}"
+    print(f"{which}: {len(grads)} LoRA gradients, worst (hip error / emulation error) = {worst:.2f}")
