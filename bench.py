@@ -195,6 +195,8 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="reduced-size model (plumbing check only; NOT a valid benchmark number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inference", action="store_true", help="skip the batch-1 inference leg (configs[1])")
+    ap.add_argument("--aloha", action="store_true", help="SURVEY.md 8(d) config 5 instead of the headline workload: ALOHA shapes (3 images, 25x14 "
+                    "chunk, proprio 14, S=1159), FiLM + diffusion head, batch 4 -- a side measurement, not the BASELINE metric")
     ap.add_argument("--eager-baseline", action="store_true", help="time the stock PyTorch-ROCm eager step instead (BASELINE.md B1) and exit")
     args = ap.parse_args()
 
@@ -226,15 +228,21 @@ def main():
                                    siglip=config_mod.VitConfig(144, 3, 2, 536))
     else:
         cfg = config_mod.OPENVLA_7B
+    if args.aloha:
+        import dataclasses
+
+        cfg = dataclasses.replace(cfg, num_images=3, chunk=25, action_dim=14, proprio_dim=14)
+        if args.batch == 8:
+            args.batch = 4           # ALOHA.md:69
     if args.eager_baseline:
         res = eager_baseline(cfg, args.batch, args.steps, args.warmup, dev)
         print(json.dumps({"metric": "fine-tune samples/s (action-chunks/s) OpenVLA-7B bf16 [torch eager baseline]", "value": res["samples_per_s"],
                           "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, **res}))
         return
     t_init = time.time()
-    sd = weights_mod.random_state_dict(cfg, dev, seed=0, lm_head=False)   # identical on every rank (DDP broadcast equivalent)
+    sd = weights_mod.random_state_dict(cfg, dev, seed=0, lm_head=False, film=args.aloha, diffusion=args.aloha)   # identical on every rank
     get, has = weights_mod.make_getter(sd, dev)
-    eng = engine_mod.VLAEngine(cfg, get, dev, lora=True, use_proprio=True, head="l1", has=has)
+    eng = engine_mod.VLAEngine(cfg, get, dev, lora=True, use_proprio=True, head="diffusion" if args.aloha else "l1", use_film=args.aloha, has=has)
     del sd, get
     torch.cuda.empty_cache()
     batch = synth.make_batch(args.batch, seed=1000 + rank, num_images=cfg.num_images, chunk=cfg.chunk, action_dim=cfg.action_dim,
@@ -244,16 +252,28 @@ def main():
     batch["pixel_values"] = batch["pixel_values"].to(dev, torch.bfloat16)
     batch["actions"] = batch["actions"].to(dev, torch.bfloat16)
     batch["proprio"] = batch["proprio"].to(dev, torch.bfloat16)
-    S = 1 + cfg.num_images * cfg.dino.n_patches + 1 + (batch["input_ids"].shape[1] - 1)
+    S = 1 + cfg.num_images * cfg.dino.n_patches + 1 + int(args.aloha) + (batch["input_ids"].shape[1] - 1)   # (+1: diffusion timestep token)
     reducer = dp_mod.GradReducer(eng.stores, world) if world > 1 else None
     eng.attach_reducer(reducer)
     if rank == 0:
         print(f"[bench] init {time.time() - t_init:.1f}s, trainable params {eng.num_trainable() / 1e6:.1f} M, S={S}, "
               f"HBM allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB", file=sys.stderr)
 
+    diffusion = None
+    if args.aloha:   # finetune.py:336-350: noise, timestep and x_t are drawn per step on the host (a chunk is 350 numbers per sample)
+        dmod = load("openvla-oft_amd.diffusion")
+        sched, enc = dmod.DDIMScheduler(50), dmod.SinusoidalPositionalEncoding(cfg.llm_dim)
+        gen = torch.Generator().manual_seed(1234 + rank)
+
     def step():
+        nonlocal diffusion
         eng.zero_grad()
-        loss_sum, count, _ = eng.train_step_fwd_bwd(batch)
+        if args.aloha:
+            noise = torch.randn(batch["actions"].shape, generator=gen)
+            ts = torch.randint(0, 50, (args.batch,), generator=gen)
+            diffusion = dict(noise=noise, noisy_actions=sched.add_noise(batch["actions"].float().cpu(), noise, ts).to(torch.bfloat16),
+                             timestep_emb=enc(ts.float()).to(torch.bfloat16))
+        loss_sum, count, _ = eng.train_step_fwd_bwd(batch, diffusion=diffusion)
         if reducer is not None:
             reducer.all_reduce()
         eng.adamw_step(lr=5e-4, grad_scale=1.0 / world)
@@ -315,7 +335,7 @@ def main():
     # engine: (1) adapters applied on the fly (the state during fine-tuning evaluation), (2) adapters merged into the base
     # weights as the reference deploys them (merge_lora_weights_and_save.py), (3) the merged forward replayed from a hipGraph.
     infer = None
-    if rank == 0 and not args.no_inference:
+    if rank == 0 and not args.no_inference and not args.aloha:
         b1 = synth.make_batch(1, seed=77, num_images=cfg.num_images, chunk=cfg.chunk, action_dim=cfg.action_dim, proprio_dim=cfg.proprio_dim)
         b1["pixel_values"] = b1["pixel_values"].to(dev, torch.bfloat16)
         b1["proprio"] = b1["proprio"].to(dev, torch.bfloat16).reshape(1, -1)
@@ -360,7 +380,8 @@ def main():
             "metric": "fine-tune samples/s (action-chunks/s) OpenVLA-7B bf16", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random weights of the OpenVLA-7B architecture, synthetic LIBERO-shaped batches)",
-            "config": {"workload": "BASELINE.json configs[2]: LoRA r=32 fine-tune step (fwd+bwd+AdamW), 2x224x224 images + proprio, L1 head" + (" [TINY MODEL - not a benchmark]" if args.tiny else ""),
+            "config": {"workload": ("SURVEY 8(d) config 5 [side measurement]: ALOHA shapes, 3x224x224 images + proprio 14, 25x14 chunk, FiLM + diffusion head (MSE), LoRA r=32 step" if args.aloha else
+                                    "BASELINE.json configs[2]: LoRA r=32 fine-tune step (fwd+bwd+AdamW), 2x224x224 images + proprio, L1 head") + (" [TINY MODEL - not a benchmark]" if args.tiny else ""),
                        "global_batch": world * args.batch, "seq_len": S, "parallelism": f"dp{world}", "mask_mode": cfg.mask_mode,
                        "final_loss": final_loss},
             "roofline": roofline, "cpu_baseline": cpu, "inference_batch1": infer}))
