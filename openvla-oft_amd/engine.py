@@ -721,6 +721,51 @@ class VLAEngine:
                 out[p.name] = getattr(p, kind)
         return out
 
+    def load_trainable(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> List[str]:
+        """Inverse of export_trainable("data"): copies reference-named tensors (lora adapters, action head, projectors, FiLM)
+        into the flat parameter buffers and re-derives the transposes / bf16 compute copies.  Returns the names not found in
+        `sd` (raises instead when strict).  finetune.py:134-156,193-209 (resume)."""
+        missing = []
+        for name, view in self.export_trainable("data").items():
+            if name in sd:
+                src = sd[name]
+                if tuple(src.shape) != tuple(view.shape):
+                    raise ValueError(f"{name}: checkpoint shape {tuple(src.shape)} != model shape {tuple(view.shape)}")
+                view.copy_(src.to(view.device, view.dtype))
+            else:
+                missing.append(name)
+        if missing and strict:
+            raise KeyError(f"{len(missing)} trainable tensors missing from the checkpoint, e.g. {missing[:3]}")
+        self.refresh_derived()
+        return missing
+
+    def optimizer_state_dict(self) -> Dict[str, torch.Tensor]:
+        """AdamW moments + step of every parameter store as flat tensors (the layout is a pure function of the config).  The
+        reference does not save optimizer state (finetune.py:584-675): this is the SURVEY.md 8f(3) extension."""
+        out: Dict[str, torch.Tensor] = {}
+        for i, st in enumerate(self.stores):
+            if not st.exp_avg:
+                st.init_optimizer()
+            out[f"store{i}.step"] = torch.tensor([st.step], dtype=torch.int64)
+            for dt in st.flat:
+                tag = "bf16" if dt == BF16 else "f32"
+                out[f"store{i}.{tag}.exp_avg"] = st.exp_avg[dt]
+                out[f"store{i}.{tag}.exp_avg_sq"] = st.exp_avg_sq[dt]
+        return out
+
+    def load_optimizer_state_dict(self, sd: Dict[str, torch.Tensor]):
+        for i, st in enumerate(self.stores):
+            if not st.exp_avg:
+                st.init_optimizer()
+            st.step = int(sd[f"store{i}.step"].item())
+            for dt in st.flat:
+                tag = "bf16" if dt == BF16 else "f32"
+                for kind, buf in (("exp_avg", st.exp_avg[dt]), ("exp_avg_sq", st.exp_avg_sq[dt])):
+                    src = sd[f"store{i}.{tag}.{kind}"]
+                    if src.numel() != buf.numel():
+                        raise ValueError(f"optimizer state store{i}.{tag}.{kind}: {src.numel()} elements, model has {buf.numel()}")
+                    buf.copy_(src.to(buf.device, buf.dtype))
+
     def num_patches_total(self, num_images: int, use_proprio: bool, use_diffusion: bool = False) -> int:
         """NUM_PATCHES of finetune.py:935-941."""
         return self.cfg.dino.n_patches * num_images + int(use_proprio) + int(use_diffusion)

@@ -29,7 +29,7 @@ from ..dp import GradReducer
 from ..engine import VLAEngine
 from ..prismatic.training.train_utils import get_current_action_mask, get_next_actions_mask
 from ..prismatic.vla import constants as C
-from ..weights import make_getter, random_state_dict, save_lora_adapter
+from ..weights import load_lora_adapter, make_getter, random_state_dict, save_lora_adapter
 
 
 @dataclass
@@ -144,25 +144,61 @@ def run_forward_pass(vla, action_head, noisy_action_projector, proprio_projector
     return loss, metrics
 
 
+_COMPONENT_PREFIXES = {"proprio_projector": "proprio_projector.", "noisy_action_projector": "noisy_action_projector.", "action_head": "action_head.",
+                       "vision_backbone": "vision_backbone."}   # FiLM scale/shift Linears (finetune.py:640-645 saves the wrapped backbone)
+
+
 def save_training_checkpoint(run_dir: Path, log_step: int, engine: VLAEngine, dataset_statistics: Optional[dict], rank: int,
-                             latest_only: bool = False) -> Path:
-    """finetune.py:584-675: `{component}--{step}_checkpoint.pt` (+ `lora_adapter/`, `dataset_statistics.json`).
-    The LoRA merge of the reference (:663-675) is a separate offline step here (W += scale * B A per adapted Linear)."""
+                             latest_only: bool = False, save_optimizer: bool = True) -> Path:
+    """finetune.py:584-675: `{component}--{step}_checkpoint.pt` (+ `lora_adapter/` in peft's format, `dataset_statistics.json`).
+    The LoRA merge of the reference (:663-675) is the separate merge_lora_weights_and_save step.  Beyond the reference:
+    `optimizer_state--{step}_checkpoint.safetensors` (AdamW moments + step counters), so a resumed run continues the same
+    trajectory instead of restarting the moments from zero."""
     ckpt = run_dir if latest_only else Path(str(run_dir) + f"--{log_step}_chkpt")
-    suffix = "latest_checkpoint.pt" if latest_only else f"{log_step}_checkpoint.pt"
+    suffix = "latest_checkpoint" if latest_only else f"{log_step}_checkpoint"
     if rank == 0:
         (ckpt / "lora_adapter").mkdir(parents=True, exist_ok=True)
         if dataset_statistics is not None:
             (ckpt / "dataset_statistics.json").write_text(json.dumps(dataset_statistics))
         exp = {k: v.detach().to("cpu") for k, v in engine.export_trainable("data").items()}
         save_lora_adapter(ckpt / "lora_adapter", exp, r=engine.cfg.lora_rank, lora_alpha=engine.cfg.lora_alpha)   # peft on-disk format
-        groups = {"proprio_projector": "proprio_projector.", "noisy_action_projector": "noisy_action_projector.", "action_head": "action_head.",
-                  "vision_backbone": "vision_backbone."}   # FiLM scale/shift Linears (finetune.py:640-645 saves the wrapped backbone)
-        for comp, prefix in groups.items():
+        for comp, prefix in _COMPONENT_PREFIXES.items():
             sd = {k[len(prefix):]: v.contiguous() for k, v in exp.items() if k.startswith(prefix) and ".lora_" not in k}
             if sd:
-                torch.save(sd, ckpt / f"{comp}--{suffix}")
+                torch.save(sd, ckpt / f"{comp}--{suffix}.pt")
+        if save_optimizer:
+            from safetensors.torch import save_file
+
+            save_file({k: v.detach().to("cpu").contiguous() for k, v in engine.optimizer_state_dict().items()},
+                      str(ckpt / f"optimizer_state--{suffix}.safetensors"))
     return ckpt
+
+
+def load_training_checkpoint(ckpt: Path, log_step: Optional[int], engine: VLAEngine, load_optimizer: bool = True) -> dict:
+    """Resume (finetune.py:134-156 `load_checkpoint(module_name, path, step)` per component + the lora adapter the reference
+    re-attaches through its merged checkpoint): reads `{component}--{step}_checkpoint.pt` (`latest` when step is None), the
+    peft adapter directory and, if present, the optimizer state.  Only `weights_only=True` / safetensors loaders are used."""
+    ckpt = Path(ckpt)
+    suffix = "latest_checkpoint" if log_step is None else f"{log_step}_checkpoint"
+    sd: Dict[str, torch.Tensor] = {}
+    adapter_dir = ckpt / "lora_adapter"
+    if adapter_dir.is_dir():
+        adapter, _ = load_lora_adapter(adapter_dir)
+        sd.update(adapter)
+    for comp, prefix in _COMPONENT_PREFIXES.items():
+        f = ckpt / f"{comp}--{suffix}.pt"
+        if f.is_file():
+            part = remove_ddp_in_checkpoint(torch.load(str(f), weights_only=True, map_location="cpu"))
+            sd.update({prefix + k: v for k, v in part.items()})
+    missing = engine.load_trainable(sd, strict=False)
+    opt = ckpt / f"optimizer_state--{suffix}.safetensors"
+    loaded_opt = False
+    if load_optimizer and opt.is_file():
+        from safetensors.torch import load_file
+
+        engine.load_optimizer_state_dict(load_file(str(opt)))
+        loaded_opt = True
+    return {"missing": missing, "optimizer": loaded_opt, "tensors": len(sd)}
 
 
 def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state_dict: Optional[Dict[str, torch.Tensor]] = None,
@@ -199,6 +235,11 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
         sched, time_enc = DDIMScheduler(cfg.num_diffusion_steps), SinusoidalPositionalEncoding(model_config.llm_dim)
         noise_gen = torch.Generator().manual_seed(7 + rank)
     log(f"# total trainable params: {engine.num_trainable()}")
+    if cfg.resume:   # finetune.py:193-209: the trainable components come from the checkpoint directory `vla_path` at `resume_step`
+        assert cfg.resume_step is not None, "resume=True needs resume_step"
+        info = load_training_checkpoint(Path(cfg.vla_path), cfg.resume_step, engine)
+        log(f"[finetune] resumed step {cfg.resume_step} from {cfg.vla_path}: {info['tensors']} tensors, optimizer state: {info['optimizer']}, "
+            f"{len(info['missing'])} trainable tensors kept at their initial values")
     reducer = GradReducer(engine.stores, world) if world > 1 else None
     engine.attach_reducer(reducer, overlap=cfg.grad_accumulation_steps == 1)   # overlap only when every backward ends a step
     if dataset is None:
