@@ -207,6 +207,17 @@ int ovla_colscale_bf16(const ovla_colscale_args* a, void* stream); /* out[m,n] =
 typedef struct { const void* pixels; void* out; int64_t ldo; int32_t B, C_total, c0, H, W, patch, n_img, img_cstride; } ovla_im2col_args;
 int ovla_im2col(const ovla_im2col_args* a, void* stream);
 
+/* Inference-side image preparation as ONE kernel (experiments/robot/openvla_utils.py:542-622 `center_crop_image`:
+ * convert_image_dtype(u8 -> f32) = x * (1/255); tf.image.crop_and_resize of the central sqrt(crop_scale) box back to out x out
+ * (TF 2.15 CropAndResize arithmetic in fp32: in_y = y1 (H-1) + i (y2-y1)(H-1)/(out-1), lerp form a + (b-a) w); clip; back to uint8
+ * as trunc(x * 255.5); then prismatic/extern/hf/processing_prismatic.py:128-145 `apply_transform`: to_tensor (/255) and
+ * per-backbone normalise, channel-stacked).  src uint8 [n_img, H, W, 3] (HWC, device) -> dst bf16 [n_img * 6, out, out]:
+ * image i -> channels [6 i, 6 i + 3) normalised with mean[0..2]/std[0..2] (DINOv2) and [6 i + 3, 6 i + 6) with mean[3..5]/std[3..5]
+ * (SigLIP).  crop == 0: the pixels are taken as they are (requires H == W == out).  Every fp32 operation is individually
+ * rounded (no FMA contraction): bit-exact against the host restatement (image_prep.center_crop_image + apply_transform). */
+typedef struct { const void* src; void* dst; int32_t n_img, H, W, out, crop; float crop_scale; float mean[6]; float std[6]; } ovla_image_prep_args;
+int ovla_image_prep(const ovla_image_prep_args* a, void* stream);
+
 /* tokens[b, pre + i, :] = patches[b, i, :] + pos[i, :] ;  tokens[b, j, :] = prefix[j, :]  (cls / register tokens)
  * (timm VisionTransformer._pos_embed with no_embed_class=True) */
 typedef struct { const void* patches; const void* pos; const void* prefix; void* tokens; int32_t B, n_patches, n_prefix, dim; } ovla_vit_embed_args;

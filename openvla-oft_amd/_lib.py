@@ -60,7 +60,11 @@ def parse_header(path: Path = HEADER_PATH):
                 while var.startswith("*"):
                     ctype_name += "*"
                     var = var[1:].strip()
-                fields.append((var, _CTYPE[ctype_name]))
+                ct = _CTYPE[ctype_name]
+                am = re.match(r"^(\w+)\s*\[\s*(\d+)\s*\]$", var)      # fixed-size array member, e.g. `float mean[6]`
+                if am:
+                    var, ct = am.group(1), ct * int(am.group(2))
+                fields.append((var, ct))
         structs[name] = fields
     text_wo_structs = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", " ", text, flags=re.S)
     functions = {}

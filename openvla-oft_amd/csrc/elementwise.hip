@@ -510,6 +510,58 @@ inline int grid_for(int64_t work_items) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------
+// image preparation (center crop via bilinear crop_and_resize -> uint8 -> dual normalisation), one thread per output pixel.
+// Arithmetic mirrors the numpy restatement operation by operation (each fp32 op rounded on its own).
+namespace {
+struct ImagePrepParams { const uint8_t* src; bf16_bits* dst; int n_img, H, W, out, crop; float ybase, ystep, xbase, xstep; float mean[6], stdv[6]; };
+
+__global__ __launch_bounds__(256) void image_prep_kernel(const ImagePrepParams p) {
+#pragma clang fp contract(off)  // one rounding per multiply / add / subtract, as numpy and TF's kernel do (plain operators: the
+                                // pragma does not reach HIP's inlined __fmul_rn & co.)
+  const int64_t total = (int64_t)p.n_img * p.out * p.out;
+  const float inv255 = 1.0f / 255.0f;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(idx % p.out), oy = (int)((idx / p.out) % p.out), img = (int)(idx / ((int64_t)p.out * p.out));
+    const uint8_t* im = p.src + (int64_t)img * p.H * p.W * 3;
+    uint8_t q[3];
+    if (p.crop) {
+      const float ty = (float)oy * p.ystep, tx = (float)ox * p.xstep;
+      const float ys = p.ybase + ty, xs = p.xbase + tx;
+      const float fy = floorf(ys), fx = floorf(xs);
+      const int y0 = (int)fy, x0 = (int)fx, y1 = (int)ceilf(ys), x1 = (int)ceilf(xs);
+      const float wy = ys - fy, wx = xs - fx;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float tl = (float)im[((int64_t)y0 * p.W + x0) * 3 + c] * inv255, tr = (float)im[((int64_t)y0 * p.W + x1) * 3 + c] * inv255;
+        const float bl = (float)im[((int64_t)y1 * p.W + x0) * 3 + c] * inv255, br = (float)im[((int64_t)y1 * p.W + x1) * 3 + c] * inv255;
+        const float dt = tr - tl, db = br - bl;
+        const float pt = dt * wx, pb = db * wx;
+        const float top = tl + pt, bot = bl + pb;
+        const float dv = bot - top;
+        const float pv = dv * wy;
+        float v = top + pv;
+        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        const float scaled = v * 255.5f;
+        q[c] = (uint8_t)scaled;                // truncation: TF convert_image_dtype(float -> uint8, saturate)
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) q[c] = im[((int64_t)oy * p.W + ox) * 3 + c];
+    }
+    const int64_t plane = (int64_t)p.out * p.out;
+    bf16_bits* o = p.dst + (int64_t)img * 6 * plane + (int64_t)oy * p.out + ox;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float x = (float)q[c] / 255.0f;
+      const float d0 = x - p.mean[c], d1 = x - p.mean[3 + c];
+      o[c * plane] = f2bf(d0 / p.stdv[c]);
+      o[(3 + c) * plane] = f2bf(d1 / p.stdv[3 + c]);
+    }
+  }
+}
+}  // namespace
+
 extern "C" int ovla_norm_fwd(const ovla_norm_fwd_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   OVLA_REQUIRE(a && a->x && a->y && a->weight, "ovla_norm_fwd: null pointer");
@@ -598,6 +650,33 @@ extern "C" int ovla_colscale_bf16(const ovla_colscale_args* a, void* stream_) {
   hipLaunchKernelGGL(colscale_kernel, dim3(grid_for((int64_t)a->rows * a->dim / 8)), dim3(256), 0, stream, (const bf16_bits*)a->x,
                      (const bf16_bits*)a->scale, (bf16_bits*)a->out, a->rows, a->dim);
   OVLA_CHECK_LAUNCH("ovla_colscale_bf16");
+  return OVLA_OK;
+}
+extern "C" int ovla_image_prep(const ovla_image_prep_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->src && a->dst, "ovla_image_prep: null pointer");
+  OVLA_REQUIRE(a->n_img > 0 && a->H > 1 && a->W > 1 && a->out > 1, "ovla_image_prep: bad shape %d x %d x %d -> %d", a->n_img, a->H, a->W, a->out);
+  OVLA_REQUIRE(a->crop || (a->H == a->out && a->W == a->out), "ovla_image_prep: without the crop the input must already be %d x %d", a->out, a->out);
+  OVLA_REQUIRE(!a->crop || a->crop_scale > 0.0f, "ovla_image_prep: crop_scale %f must be positive", (double)a->crop_scale);
+  ImagePrepParams p;
+  p.src = (const uint8_t*)a->src; p.dst = (bf16_bits*)a->dst; p.n_img = a->n_img; p.H = a->H; p.W = a->W; p.out = a->out; p.crop = a->crop;
+  {   // the box and the sampling grid in fp32, one rounding per operation, as TF computes them (volatile: no host-side contraction)
+    volatile float side = sqrtf(a->crop_scale);
+    side = side < 0.0f ? 0.0f : (side > 1.0f ? 1.0f : side);
+    volatile float o1 = (1.0f - side) / 2.0f;
+    volatile float o2 = o1 + side;
+    volatile float span = o2 - o1;
+    volatile float sy = span * (float)(a->H - 1), sx = span * (float)(a->W - 1);
+    p.ystep = sy / (float)(a->out - 1); p.xstep = sx / (float)(a->out - 1);
+    volatile float by = o1 * (float)(a->H - 1), bx = o1 * (float)(a->W - 1);
+    p.ybase = by; p.xbase = bx;
+  }
+  for (int i = 0; i < 6; ++i) {
+    OVLA_REQUIRE(a->std[i] != 0.0f, "ovla_image_prep: std[%d] == 0", i);
+    p.mean[i] = a->mean[i]; p.stdv[i] = a->std[i];
+  }
+  hipLaunchKernelGGL(image_prep_kernel, dim3(grid_for((int64_t)a->n_img * a->out * a->out)), dim3(256), 0, stream, p);
+  OVLA_CHECK_LAUNCH("ovla_image_prep");
   return OVLA_OK;
 }
 extern "C" int ovla_im2col(const ovla_im2col_args* a, void* stream_) {

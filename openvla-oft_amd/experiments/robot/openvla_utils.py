@@ -16,7 +16,7 @@ from typing import Any, Dict, List, Optional
 import numpy as np
 import torch
 
-from ... import image_prep
+from ... import image_prep, ops
 from ...config import OPENVLA_7B, VLAConfig
 from ...modeling import DiffusionActionHead, L1RegressionActionHead, NoisyActionProjector, OpenVLAForActionPrediction, ProprioProjector
 from ...prismatic.vla import constants as C
@@ -91,13 +91,16 @@ def get_action_head(cfg: Any, llm_dim: int):
 class PrismaticProcessor:
     """processor(prompt, image) -> {"input_ids", "attention_mask", "pixel_values"} (processing_prismatic.py:175-252)."""
 
-    def __init__(self, tokenizer):
+    def __init__(self, tokenizer, device_image_prep: bool = True):
         self.tokenizer = tokenizer
+        self.device_image_prep = device_image_prep   # get_vla_action prepares the images on the GPU (ops.image_prep) when it can
+
+    def tokenize(self, text: str) -> Dict[str, torch.Tensor]:
+        ids = list(self.tokenizer(text))
+        return {"input_ids": torch.tensor([ids], dtype=torch.int64), "attention_mask": torch.ones((1, len(ids)), dtype=torch.bool)}
 
     def __call__(self, text: str, image: np.ndarray):
-        ids = list(self.tokenizer(text))
-        return {"input_ids": torch.tensor([ids], dtype=torch.int64), "attention_mask": torch.ones((1, len(ids)), dtype=torch.bool),
-                "pixel_values": image_prep.apply_transform(np.asarray(image))[None]}
+        return {**self.tokenize(text), "pixel_values": image_prep.apply_transform(np.asarray(image))[None]}
 
 
 def get_processor(cfg: Any, tokenizer=None) -> PrismaticProcessor:
@@ -125,6 +128,18 @@ def normalize_proprio(proprio: np.ndarray, norm_stats: Dict[str, Any]) -> np.nda
 prepare_images_for_vla = image_prep.prepare_images_for_vla
 
 
+def device_pixel_values(images: List[np.ndarray], cfg: Any) -> torch.Tensor:
+    """prepare_images_for_vla + processor(...)["pixel_values"] of every image, concatenated on dim 1, computed on the device: the
+    uint8 frames go to HBM as they are (150 KB each); center crop, uint8 re-quantisation and both backbones' normalisations are ONE
+    kernel (ovla_image_prep), bit-identical to image_prep.center_crop_image + apply_transform.  -> bf16 [1, 6 * n, 224, 224]."""
+    for image in images:
+        image_prep.check_image_format(image)
+        if image.shape != (image_prep.OPENVLA_IMAGE_SIZE, image_prep.OPENVLA_IMAGE_SIZE, 3):
+            raise NotImplementedError("resize_image_for_policy (TF jpeg + lanczos3) is not available in this port; pass 224x224 images")
+    frames = torch.from_numpy(np.ascontiguousarray(np.stack(images))).to(DEVICE, non_blocking=True)
+    return ops.image_prep(frames, crop=bool(cfg.center_crop))
+
+
 def get_vla_action(cfg: Any, vla, processor: Any, obs: Dict[str, Any], task_label: str, action_head=None, proprio_projector=None,
                    noisy_action_projector=None, use_film: bool = False) -> List[np.ndarray]:
     """openvla_utils.py:711-796.  Note: like the reference, overwrites obs["state"] with the normalised proprio."""
@@ -132,13 +147,18 @@ def get_vla_action(cfg: Any, vla, processor: Any, obs: Dict[str, Any], task_labe
         all_images = [obs["full_image"]]
         if cfg.num_images_in_input > 1:
             all_images.extend([obs[k] for k in obs.keys() if "wrist" in k or "camera_gripper_image" in k])
-        all_images = prepare_images_for_vla(all_images, cfg)
-        primary = all_images.pop(0)
         prompt = f"In: What action should the robot take to {task_label.lower()}?\nOut:"
-        inputs = processor(prompt, primary)
-        if all_images:
-            wrist = [processor(prompt, im)["pixel_values"] for im in all_images]
-            inputs["pixel_values"] = torch.cat([inputs["pixel_values"]] + wrist, dim=1)
+        if (isinstance(processor, PrismaticProcessor) and processor.device_image_prep and torch.cuda.is_available()
+                and vla.config.image_sizes[0] == image_prep.OPENVLA_IMAGE_SIZE):
+            inputs = processor.tokenize(prompt)
+            inputs["pixel_values"] = device_pixel_values(all_images, cfg)
+        else:
+            all_images = prepare_images_for_vla(all_images, cfg)
+            primary = all_images.pop(0)
+            inputs = processor(prompt, primary)
+            if all_images:
+                wrist = [processor(prompt, im)["pixel_values"] for im in all_images]
+                inputs["pixel_values"] = torch.cat([inputs["pixel_values"]] + wrist, dim=1)
         proprio = None
         if cfg.use_proprio:
             obs["state"] = normalize_proprio(obs["state"], vla.norm_stats[cfg.unnorm_key]["proprio"])

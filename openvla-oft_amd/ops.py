@@ -383,6 +383,22 @@ def masked_mean(x, row_mask, B, L, dim):
     return out
 
 
+def image_prep(images_u8, *, crop: bool, crop_scale: float = 0.9, out_size: int = 224,
+               mean=(0.485, 0.456, 0.406, 0.5, 0.5, 0.5), std=(0.229, 0.224, 0.225, 0.5, 0.5, 0.5)):
+    """uint8 [n_img, H, W, 3] (device) -> bf16 [1, 6 * n_img, out, out] pixel_values: center crop (TF crop_and_resize rule) +
+    uint8 re-quantisation + DINOv2 / SigLIP normalisation in one launch (openvla_utils.py:542-622, processing_prismatic.py:128-145)."""
+    assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3 and images_u8.is_contiguous() and images_u8.is_cuda
+    n, H, W, _ = images_u8.shape
+    out = torch.empty((1, 6 * n, out_size, out_size), dtype=BF16, device=images_u8.device)
+    g = STRUCTS["ovla_image_prep_args"]()
+    g.src, g.dst, g.n_img, g.H, g.W, g.out, g.crop = images_u8.data_ptr(), out.data_ptr(), n, H, W, out_size, int(crop)
+    g.crop_scale = float(crop_scale)
+    for i in range(6):
+        g.mean[i], g.std[i] = mean[i], std[i]
+    _lib.call("ovla_image_prep", g, _stream())
+    return out
+
+
 def assemble_multimodal(ids, labels, table, patches, *, A, noisy=None, ignore_index=-100, action_token_begin=31743, action_dim=7):
     """ids/labels int64 [B,L]; table bf16 [V,D]; patches bf16 [B,P,D] -> (out [B,P+L,D], action_rows int32 [B,A]:
     flattened row of the hidden state that predicts each action slot)."""

@@ -85,6 +85,15 @@ def test_get_vla_action_glue(world):
     assert np.all(np.isfinite(np.stack(actions)))
     with pytest.raises(AssertionError, match="Incorrect image format"):
         utils.get_vla_action(cfg, vla, proc, {**obs, "full_image": obs["full_image"].astype(np.float32)}, "x", action_head=head, proprio_projector=pp)
+    # the device image path (one ovla_image_prep launch; taken for 224-pixel models) equals the host functions bit for bit
+    ip = load("openvla-oft_amd.image_prep")
+    imgs = [obs["full_image"], obs["wrist_image"]]
+    for crop in (True, False):
+        c = types.SimpleNamespace(center_crop=crop)
+        host = torch.cat([ip.apply_transform(im)[None] for im in ip.prepare_images_for_vla(list(imgs), c)], dim=1).to(BF)
+        assert torch.equal(utils.device_pixel_values(imgs, c).cpu(), host)
+    with pytest.raises(NotImplementedError, match="224x224"):
+        utils.device_pixel_values([np.zeros((256, 256, 3), np.uint8)], cfg)
 
 
 def test_autograd_bridge_equals_fused_step(world):

@@ -502,3 +502,27 @@ def test_transpose_and_casts(ops, dev):
     assert torch.equal(ops.add(a, b), (a.float() + b.float()).to(BF))
     s = rnd(128, dev=dev)
     assert torch.equal(ops.colscale(a, s), (a.float() * s.float()).to(BF))
+
+
+@pytest.mark.parametrize("crop", [True, False])
+@pytest.mark.parametrize("hw", [(224, 224), (256, 320)])
+def test_image_prep_bit_exact_vs_oracle(ops, dev, crop, hw):
+    """ovla_image_prep (center crop by TF's crop_and_resize rule -> uint8 -> DINOv2 / SigLIP normalisation, one launch)
+    against the numpy restatement in the oracle: bit-exact (every fp32 op is individually rounded on both sides)."""
+    import numpy as np
+    from oracle import vla_oracle as vo
+
+    H, W = hw
+    if not crop and (H, W) != (224, 224):
+        pytest.skip("without the crop the input must already be 224 x 224")
+    rng = np.random.default_rng(H * 7 + W + int(crop))
+    imgs = rng.integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+    imgs[0, :8] = 255; imgs[1, :, :8] = 0                      # saturated borders
+    got = ops.image_prep(torch.from_numpy(imgs).to(dev), crop=crop)
+    assert got.shape == (1, 18, 224, 224) and got.dtype == BF
+    ref = []
+    for im in imgs:
+        q = vo.crop_and_resize_center(im) if crop else im
+        ref.append(vo.image_transform(q, (vo.IMAGENET_MEAN, vo.SIGLIP_MEAN), (vo.IMAGENET_STD, vo.SIGLIP_STD)))
+    ref = torch.cat(ref, 0)[None].to(BF)
+    assert torch.equal(got.cpu(), ref), f"{(got.cpu() != ref).sum().item()} of {ref.numel()} values differ"
