@@ -16,6 +16,7 @@
 //   * block ids are remapped so each XCD (private L2) owns a contiguous band of tiles, grouped 8 tile-rows deep.
 #include "common.h"
 #include <type_traits>
+#include <algorithm>
 #include <stdarg.h>
 
 namespace {
@@ -651,27 +652,47 @@ static int num_cus() {
 }
 
 // Hybrid schedule of one tile config: whole rounds of the chip as full tiles, the partial last round split along K.
-// The same cost model (seconds) picks the split and, in auto mode, the tile config itself.  Constants calibrated on
-// MI355X (tools/gemm_sweep.py): sustained in-loop rate per config and a fixed per-workgroup cost t0 (prologue latency +
-// epilogue), slab traffic at ~5 TB/s (mostly Infinity-Cache resident) + the reduce launch.
+// ONE cost model (seconds) picks the split and, in auto mode, the tile config itself.  Per config (calibrated on MI355X with
+// tools/gemm_sweep.py, gemm_m608.py, gemm_small_m.py): `rate` = sustained in-loop FLOP/s with every CU saturated, `t0` = fixed
+// per-workgroup cost (prologue latency + epilogue), `tk1` = time per K tile of a workgroup that has its CU to itself (its own
+// latency chain: a lone 4-wave 128x128 workgroup needs 0.86 us per K tile, two sharing a CU 0.95 us for both).  A round with u
+// units on C CUs puts w = min(bpc, ceil(u / C)) workgroups on a CU and takes  Tk * max(tk1, w * tkc) + t0.
+struct TileCfg { int id, BM, BN, bpc; double rate, t0, tk1; };
+static const TileCfg kTileCfgs[] = {
+    {17, 256, 256, 1, 1.30e15, 7e-6, 0.0},
+    {1, 128, 128, 2, 1.13e15, 4e-6, 0.86e-6},
+    {2, 64, 128, 3, 0.90e15, 3e-6, 0.57e-6},
+    {5, 128, 32, 4, 0.60e15, 3e-6, 0.53e-6},
+};
+static const TileCfg& tile_cfg(int BM, int BN) {
+  for (const TileCfg& c : kTileCfgs)
+    if (c.BM == BM && c.BN == BN) return c;
+  static const TileCfg generic = {0, 128, 128, 1, 0.9e15, 5e-6, 0.0};   // experimental configs: no hybrid tuning
+  return generic;
+}
+
 struct HybridPlan { int full_tiles, rem_tiles, rem_splits; double est; };
 
-static HybridPlan plan_hybrid(int M, int N, double ktot, int T, int BM, int BN, int slots, int64_t ws_floats) {
-  const bool big = BM >= 256 && BN >= 256;
-  const double rate = (big ? 1.3e15 : 1.13e15) / slots, t0 = big ? 7e-6 : 4e-6;
-  const int tiles = cdiv(M, BM) * cdiv(N, BN);
-  const double tt = 2.0 * BM * BN * ktot / rate;
+static HybridPlan plan_hybrid(int M, int N, int T, const TileCfg& c, int64_t ws_floats) {
+  const int C = num_cus(), slots = C * c.bpc;
+  const double tkc = 2.0 * c.BM * c.BN * BK / (c.rate / C);
+  auto round_time = [&](int units, int tk) {
+    const int w = std::min(c.bpc, cdiv(units, C));
+    return tk * std::max(c.tk1, w * tkc) + c.t0;
+  };
+  const int tiles = cdiv(M, c.BM) * cdiv(N, c.BN);
   HybridPlan pl{tiles, 0, 1, 0.0};
   const int full_rounds = tiles / slots, rem = tiles % slots;
-  pl.est = full_rounds * (tt + t0);
+  pl.est = full_rounds * round_time(slots, T);
   if (rem == 0) return pl;
-  double best_t = tt + t0;   // unsplit: one more (partial) round
+  double best_t = round_time(rem, T);   // unsplit: one more (partial) round
   int best = 1;
-  if (rem * 4 <= slots * 3 && ws_floats > 0) {
+  if (ws_floats > 0) {
     for (int sp = 2; sp <= 8 && sp * 4 <= T; ++sp) {
-      if ((int64_t)rem * sp * BM * BN > ws_floats) break;
-      const int rounds = (rem * sp + slots - 1) / slots;
-      const double t = rounds * (tt / sp + t0) + 1.0 * rem * sp * (4.0 * BM * BN) / 5e12 + 5e-6;   // slab writes overlap; the reduce reads them
+      if ((int64_t)rem * sp * c.BM * c.BN > ws_floats) break;
+      const int units = rem * sp, tk = cdiv(T, sp);
+      const double t = (units <= slots ? round_time(units, tk) : cdiv(units, slots) * round_time(slots, tk)) +
+                       1.0 * rem * sp * (4.0 * c.BM * c.BN) / 5e12 + 5e-6;   // slab writes overlap; the reduce kernel reads them
       if (t < best_t) { best_t = t; best = sp; }
     }
   }
@@ -703,9 +724,8 @@ int launch_cfg(GemmParams& p, hipStream_t stream, int64_t ws_bytes = 0, bool hyb
   p.rem_tiles = 0;
   p.rem_splits = 1;
   if (hybrid && splits == 1 && p.ws != nullptr) {
-    const int bpc = lds <= 80 * 1024 ? 2 : 1;          // workgroups per CU (160 KiB LDS)
     static_assert((size_t)WM * WN * 32 * (BN / WN + 4) * sizeof(float) <= 160 * 1024, "epilogue slabs exceed LDS");
-    const HybridPlan pl = plan_hybrid(p.M, p.N, (double)p.K + p.K2, p.T1 + p.T2, BM, BN, num_cus() * bpc, ws_bytes / 4);
+    const HybridPlan pl = plan_hybrid(p.M, p.N, p.T1 + p.T2, tile_cfg(BM, BN), ws_bytes / 4);
     p.full_tiles = pl.full_tiles; p.rem_tiles = pl.rem_tiles; p.rem_splits = pl.rem_splits;
   }
   const unsigned nblk = p.rem_tiles > 0 ? (unsigned)(p.full_tiles + p.rem_tiles * p.rem_splits) : (unsigned)(tiles * splits);
@@ -824,22 +844,21 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     if (p.N <= 32 || p.a_group_n == 32) { tile = 5; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 128) * cdiv(p.N, 32)); }
     else if (p.a_group_n > 0) { tile = 1; }
     else if (p.M <= 64 || p.N <= 128) { tile = 2; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 64) * cdiv(p.N, 128)); }
-    else {   // 256x256 (1 workgroup/CU) or 128x128 (2/CU), whichever the hybrid-schedule cost model predicts faster
+    else {   // 256x256 / 128x128 / 64x128 / 128x32 tiles, whichever the hybrid-schedule cost model predicts fastest
       hybrid = true;
-      tile = 1;
-      if (p.k2_group_n == 0 || p.k2_group_n % 256 == 0) {
-        const double ktot = (double)p.K + p.K2;
-        const HybridPlan big = plan_hybrid(p.M, p.N, ktot, T, 256, 256, num_cus(), wsb / 4);
-        const HybridPlan small = plan_hybrid(p.M, p.N, ktot, T, 128, 128, 2 * num_cus(), wsb / 4);
-        if (big.est < small.est) tile = 17;
+      double best = 1e30;
+      for (const TileCfg& c : kTileCfgs) {
+        if (p.k2_group_n > 0 && p.k2_group_n % c.BN != 0) continue;
+        const HybridPlan pl = plan_hybrid(p.M, p.N, T, c, wsb / 4);
+        if (pl.est < best) { best = pl.est; tile = c.id; }
       }
     }
   }
   switch (tile) {
     case 1: return launch_cfg<128, 128, 2, 2>(p, stream, wsb, hybrid);
-    case 2: return launch_cfg<64, 128, 1, 4>(p, stream);
+    case 2: return launch_cfg<64, 128, 1, 4>(p, stream, wsb, hybrid);
     case 3: return launch_cfg<256, 128, 4, 2>(p, stream);
-    case 5: return launch_cfg<128, 32, 4, 1>(p, stream);
+    case 5: return launch_cfg<128, 32, 4, 1>(p, stream, wsb, hybrid);
     case 10: return launch_pipe<256, 256, 2, 4, 4>(p, stream);
     case 11: return launch_pipe<256, 128, 2, 4, 5>(p, stream);
     case 12: return launch_pipe<256, 128, 4, 2, 5>(p, stream);
@@ -850,6 +869,8 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     case 17: return launch_cfg<256, 256, 4, 2>(p, stream, wsb, hybrid);
     case 117: return launch_cfg<256, 256, 4, 2>(p, stream, wsb, true);
     case 101: return launch_cfg<128, 128, 2, 2>(p, stream, wsb, true);
+    case 102: return launch_cfg<64, 128, 1, 4>(p, stream, wsb, true);
+    case 105: return launch_cfg<128, 32, 4, 1>(p, stream, wsb, true);
     default: ovla_set_error("ovla_gemm_bf16: unknown tile id %d", tile); return OVLA_EINVAL;
   }
 }

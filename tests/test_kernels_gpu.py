@@ -133,7 +133,9 @@ def test_gemm_split_k(ops, dev, split_k, tile):
     close(out, ref, what=f"split_k {split_k}")
 
 
-@pytest.mark.parametrize("M,N,K,tile", [(4864, 4096, 1024, 117), (4864, 4096, 1024, 0), (1300, 1152, 512, 101), (2500, 2304, 2048, 117), (300, 520, 256, 101)])
+@pytest.mark.parametrize("M,N,K,tile", [(4864, 4096, 1024, 117), (4864, 4096, 1024, 0), (1300, 1152, 512, 101), (2500, 2304, 2048, 117), (300, 520, 256, 101),
+                                        (522, 1024, 4096, 102), (522, 3072, 1024, 105), (608, 4096, 4096, 105), (522, 1024, 4096, 0), (512, 4304, 1152, 0),
+                                        (608, 4096, 11008, 0), (1000, 2304, 1088, 102)])
 def test_gemm_hybrid_schedule(ops, dev, M, N, K, tile):
     """Full rounds data-parallel + remainder tiles split along K (partial slabs + reduce kernel with the epilogue)."""
     torch.manual_seed(M + N + K)
