@@ -84,6 +84,11 @@ typedef struct {
   int64_t workspace_bytes;       /* (hybrid remainder split, skinny-N split-K) when tile == 0; may be NULL/0 */
 } ovla_gemm_args;
 
+/* The schedule `tile = 0` would pick for a dense GEMM (no skinny / small-M special case): tile id (17 = 256x256, 1 = 128x128,
+ * 2 = 64x128, 5 = 128x32), how many tiles run whole, how many are split along K and how many ways, and the cost model's estimate.
+ * Host-only (no launch): lets callers and tests inspect the decision. */
+int ovla_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t K2, int32_t k2_group_n, int64_t workspace_bytes, int32_t* tile,
+                   int32_t* full_tiles, int32_t* rem_tiles, int32_t* rem_splits, double* est_seconds);
 int64_t ovla_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream);
 

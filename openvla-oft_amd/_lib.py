@@ -21,6 +21,7 @@ _CTYPE = {
     "int32_t*": ctypes.c_void_p,
     "int64_t*": ctypes.c_void_p,
     "uint8_t*": ctypes.c_void_p,
+    "double*": ctypes.c_void_p,
     "char*": ctypes.c_char_p,
     "int64_t": ctypes.c_int64,
     "int32_t": ctypes.c_int32,

@@ -701,6 +701,20 @@ static HybridPlan plan_hybrid(int M, int N, int T, const TileCfg& c, int64_t ws_
   return pl;
 }
 
+static int pick_tile(int M, int N, int T, int k2_group_n, int64_t ws_floats, HybridPlan* out) {
+  double best = 1e30;
+  int tile = 1;
+  for (const TileCfg& c : kTileCfgs) {
+    if (k2_group_n > 0 && k2_group_n % c.BN != 0) continue;
+    const HybridPlan pl = plan_hybrid(M, N, T, c, ws_floats);
+    if (pl.est < best) {
+      best = pl.est; tile = c.id;
+      if (out) *out = pl;
+    }
+  }
+  return tile;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(GemmParams& p, hipStream_t stream, int64_t ws_bytes = 0, bool hybrid = false) {
   p.tiles_m = cdiv(p.M, BM);
@@ -778,6 +792,18 @@ int launch_pipe(GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
+extern "C" int ovla_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t K2, int32_t k2_group_n, int64_t workspace_bytes, int32_t* tile,
+                              int32_t* full_tiles, int32_t* rem_tiles, int32_t* rem_splits, double* est_seconds) {
+  OVLA_REQUIRE(M > 0 && N > 0 && K > 0 && K2 >= 0 && tile, "ovla_gemm_plan: bad arguments");
+  HybridPlan pl{0, 0, 1, 0.0};
+  *tile = pick_tile(M, N, cdiv(K, BK) + (K2 > 0 ? cdiv(K2, BK) : 0), k2_group_n, workspace_bytes / 4, &pl);
+  if (full_tiles) *full_tiles = pl.full_tiles;
+  if (rem_tiles) *rem_tiles = pl.rem_tiles;
+  if (rem_splits) *rem_splits = pl.rem_splits;
+  if (est_seconds) *est_seconds = pl.est;
+  return OVLA_OK;
+}
+
 extern "C" int64_t ovla_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
   return split_k > 1 ? (int64_t)split_k * M * N * 4 : 0;
 }
@@ -846,12 +872,7 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     else if (p.M <= 64 || p.N <= 128) { tile = 2; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 64) * cdiv(p.N, 128)); }
     else {   // 256x256 / 128x128 / 64x128 / 128x32 tiles, whichever the hybrid-schedule cost model predicts fastest
       hybrid = true;
-      double best = 1e30;
-      for (const TileCfg& c : kTileCfgs) {
-        if (p.k2_group_n > 0 && p.k2_group_n % c.BN != 0) continue;
-        const HybridPlan pl = plan_hybrid(p.M, p.N, T, c, wsb / 4);
-        if (pl.est < best) { best = pl.est; tile = c.id; }
-      }
+      tile = pick_tile(p.M, p.N, T, p.k2_group_n, wsb / 4, nullptr);
     }
   }
   switch (tile) {

@@ -150,3 +150,38 @@ def test_save_sharded_layout(tmp_path):
         got.update(load_file(str(f)))
     assert all(torch.equal(got[k], sd[k]) for k in sd)
     assert [f.name for f in m.save_sharded(sd, tmp_path / "b")] == ["model.safetensors"]
+
+
+def test_gemm_schedule_decisions():
+    """ovla_gemm_plan: the host-side cost model behind `tile = 0` (no launch, runs without a GPU: the CU count falls back to 256).
+    Pins the decisions the measurements in tools/gemm_sweep.py / gemm_m608.py / gemm_small_m.py justified."""
+    import ctypes
+
+    lib = importlib.import_module("openvla-oft_amd._lib").lib()
+
+    def plan(M, N, K, K2=0, group=0):
+        t, f, r, s = (ctypes.c_int32() for _ in range(4))
+        e = ctypes.c_double()
+        assert lib.ovla_gemm_plan(M, N, K, K2, group, 96 << 20, ctypes.byref(t), ctypes.byref(f), ctypes.byref(r), ctypes.byref(s), ctypes.byref(e)) == 0
+        return t.value, f.value, r.value, s.value, e.value
+
+    dims = {17: (256, 256), 1: (128, 128), 2: (64, 128), 5: (128, 32)}
+    cases = {  # (M, N, K, K2, k2_group_n) -> expected tile
+        (4864, 12288, 4096, 32, 4096): 17, (4864, 22016, 4096, 32, 11008): 17, (4864, 4096, 11008, 32, 0): 17, (4864, 4096, 4096, 32, 0): 17,   # Llama, B = 8
+        (4176, 3072, 1024, 32, 0): 17, (4176, 1024, 1024, 32, 0): 2,                                                                             # ViT, B = 8
+        (608, 12288, 4096, 0, 0): 1, (608, 4096, 4096, 0, 0): 1, (608, 4096, 11008, 0, 0): 1,                                                  # Llama, batch-1 inference
+        (522, 3072, 1024, 0, 0): 5, (512, 1152, 1152, 0, 0): 5, (522, 1024, 4096, 0, 0): 2,                                                     # ViT, batch-1 inference
+    }
+    for (M, N, K, K2, g), want in cases.items():
+        tile, full, rem, sp, est = plan(M, N, K, K2, g)
+        bm, bn = dims[tile]
+        tiles = -(-M // bm) * -(-N // bn)
+        assert tile == want, f"{(M, N, K)}: tile {tile}, expected {want}"
+        assert (full + rem == tiles) if rem else (full == tiles and sp == 1)
+        assert 1 <= sp <= 8 and 0 < est < 5e-3
+        if g:
+            assert g % bn == 0, "a LoRA group never straddles an N tile"
+    # the o-proj shape: 304 tiles of 256x256 = one full round of the 256 CUs + 48 tiles split along K over the idle CUs
+    assert plan(4864, 4096, 4096, 32)[1:4] == (256, 48, 5)
+    # more work never gets cheaper
+    assert plan(4864, 8192, 4096)[4] > plan(4864, 4096, 4096)[4] and plan(4864, 4096, 8192)[4] > plan(4864, 4096, 4096)[4]
