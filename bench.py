@@ -56,7 +56,22 @@ def cpu_baseline(cfg, S, train_flops_per_sample):
     host cores.  Its measured FLOP rate is converted to samples/s of the full step by the FLOP ratio."""
     from oracle import vla_oracle as vo
 
-    cores = os.cpu_count() or 1
+    # the threads this process may actually run on (a 1-GPU box grants a CPU share, not the host's whole core count:
+    # one thread per *granted* core; oversubscribing 256 threads onto 16 cores ran 10x slower)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    quota = None
+    try:   # cgroup v2 CPU quota, if any
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(int(q) / int(per)))
+    except Exception:
+        pass
+    if quota:
+        cores = min(cores, quota)
+    cores = min(cores, int(os.environ.get("OVLA_CPU_BASELINE_THREADS", "64")))
     torch.set_num_threads(cores)
     ocfg = vo.OracleConfig(llm_dim=cfg.llm_dim, llm_layers=1, llm_heads=cfg.llm_heads, llm_ff=cfg.llm_ff, vocab=cfg.vocab)
     g = torch.Generator().manual_seed(0)
@@ -314,17 +329,28 @@ def main():
             d = fam.setdefault(family, [0, 0.0, 0.0])
             d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fl
         ops.PROFILE = None
-        n, ms, fl = fam["gemm_nt"]
+        # the dominant kernel = the gemm_nt instance with the most time in the step (ops._gemm_family names the instance each
+        # launch runs: t17 = gemm_nt_kernel<256,256,4,2>, t1 = <128,128,2,2>, t2 = <64,128,1,4>, t5 = <128,32,4,1>; a launch's
+        # events also cover its split-K / hybrid reduce kernel)
+        inst = {"gemm_nt_t17": "gemm_nt_kernel<256,256,4,2>", "gemm_nt_t1": "gemm_nt_kernel<128,128,2,2>", "gemm_nt_t2": "gemm_nt_kernel<64,128,1,4>",
+                "gemm_nt_t5": "gemm_nt_kernel<128,32,4,1>"}
+        gemms = {k: v for k, v in fam.items() if k.startswith("gemm_nt")}
+        dom = max(gemms, key=lambda k: gemms[k][1])
+        n, ms, fl = gemms[dom]
         achieved = fl / (ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 NT GEMM + LoRA K-extension, all tile configs)", "achieved": achieved,
-                    "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+        all_n, all_ms, all_fl = (sum(v[i] for v in gemms.values()) for i in range(3))
+        roofline = {"bound": "mfma", "kernel": inst.get(dom, dom) + " (bf16 NT GEMM + LoRA K-extension + fused epilogue; incl. its hybrid-remainder reduce)",
+                    "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                     # HBM-side bytes per launch from PMC counters cannot be collected from inside this process; the value below is
                     # the measured, gfx950-corrected FETCH_SIZE*2 + WRITE_SIZE of the most expensive shape (gate|up forward,
                     # 4864x22016x4096; 4.34e8 algorithmic bytes), see profiles/r01_pmc_gemm_gate_up.md
                     "traffic": 1.754e9 if not args.tiny else None,
-                    "launches_per_step": n, "avg_launch_us": 1e3 * ms / n, "flops_per_step": fl,
+                    "launches_per_step": n, "avg_launch_us": 1e3 * ms / n, "flops_per_step": fl, "ms_per_step": ms,
+                    "all_gemm_nt": {"launches": all_n, "ms": all_ms, "flops_per_step": all_fl, "tflops": all_fl / (all_ms * 1e-3) / 1e12,
+                                    "by_instance": {inst.get(k, k): {"launches": v[0], "ms": v[1], "tflops": v[2] / (v[1] * 1e-3) / 1e12}
+                                                    for k, v in sorted(gemms.items())}},
                     "other_kernels": {k: {"launches": v[0], "ms": v[1], "tflops": (v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else None)}
-                                      for k, v in fam.items() if k != "gemm_nt"},
+                                      for k, v in fam.items() if not k.startswith("gemm_nt")},
                     "event_timed_ms_per_step": sum(v[1] for v in fam.values())}
         fwd_f, train_f = flops_per_sample(cfg, S, cfg.num_images)
         roofline["step_tflops_per_sample"] = train_f / 1e12
