@@ -54,6 +54,10 @@ int ovla_check_device(int device);
  * Epilogue order (each step rounds to bf16 like the reference's separate PyTorch ops do):
  *   v = alpha * acc;  v += bias[n];  [C_pre = v];  v = act(v);  v *= colscale[n];  v += residual[m,n];
  *   v = v * (1 + film_gamma[m / film_rows, n]) + film_beta[...]  ->  C
+ * Backward epilogues (the data-gradient GEMM applies the producing activation's derivative instead of a separate pass):
+ *   dact_mode 1: C[m,n] = v * act'(dact_src[m,n])               (dact_act: GELU / ReLU / SiLU / GELU-tanh; timm Mlp, projector)
+ *   dact_mode 2: SwiGLU: g = dact_src[m,n], u = dact_src[m,n+N]; C[m,n] = v*u*silu'(g), C[m,n+N] = v*silu(g); C is [M,2N]
+ *     (LlamaMLP down_proj(silu(gate) * up): the gradient of the fused gate|up pre-activations)
  * Requirements: K % 8 == 0, K2 % 8 == 0, N % 8 == 0, ld* % 8 == 0, 16-byte aligned base pointers.
  * split_k > 1 needs `workspace` of ovla_gemm_workspace_bytes() bytes.
  */
@@ -80,6 +84,8 @@ typedef struct {
   int32_t split_k;               /* <=1: none */
   int32_t tile;                  /* 0: auto; otherwise forces a tile configuration (tests / tuning) */
   float alpha;                   /* scales the accumulator (LoRA alpha/r); 0 means 1 */
+  const void* dact_src; int64_t ld_dact;   /* optional saved pre-activations for the backward epilogues above */
+  int32_t dact_mode, dact_act;
   void* workspace;               /* fp32 scratch: [split_k, M, N] when split_k > 1; also enables the auto schedules */
   int64_t workspace_bytes;       /* (hybrid remainder split, skinny-N split-K) when tile == 0; may be NULL/0 */
 } ovla_gemm_args;

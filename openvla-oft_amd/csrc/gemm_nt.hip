@@ -39,6 +39,7 @@ struct GemmParams {
   float* ws;
   int tiles_m, tiles_n, T1, T2;
   int fast_addr;  // 1: every staged byte offset fits in 32 bits (host-checked)
+  const bf16_bits* dact_src; int64_t ld_dact; int dact_mode, dact_act;   // backward epilogues (ovla.h)
   int dbg;  // timing ablations (tools/gemm_ablate.py): bit0 = stage only the first two K tiles, bit1 = read fragments once, bit2 = every workgroup stages tile (0,0): all L2 hits
   int full_tiles, rem_tiles, rem_splits;  // hybrid schedule: tiles >= full_tiles are split rem_splits ways along K
 };
@@ -149,6 +150,23 @@ OVLA_DEV void epilogue_store(const GemmParams& p, int m, int n, f32x4 v) {
       const float one_plus = bfround(1.0f + bf2f((bf16_bits)g[j]));
       v[j] = bfround(bfround(v[j] * one_plus) + bf2f((bf16_bits)b[j]));
     }
+  }
+  if (p.dact_mode == 1) {          // dz = dh * act'(z): same arithmetic as act_bwd_kernel on the bf16-rounded dh
+    const bf16x4_bits z = *reinterpret_cast<const bf16x4_bits*>(p.dact_src + (int64_t)m * p.ld_dact + n);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = bfround(v[j]) * act_grad(bf2f((bf16_bits)z[j]), p.dact_act);
+  } else if (p.dact_mode == 2) {   // SwiGLU backward (swiglu_bwd_kernel's arithmetic): two outputs per element
+    const bf16x4_bits g4 = *reinterpret_cast<const bf16x4_bits*>(p.dact_src + (int64_t)m * p.ld_dact + n);
+    const bf16x4_bits u4 = *reinterpret_cast<const bf16x4_bits*>(p.dact_src + (int64_t)m * p.ld_dact + p.N + n);
+    bf16x4_bits du;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = bfround(v[j]), g = bf2f((bf16_bits)g4[j]), u = bf2f((bf16_bits)u4[j]);
+      const float s = sigmoidf_(g);
+      du[j] = (short)f2bf(d * bfround(g * s));
+      v[j] = d * u * (s * (1.f + g * (1.f - s)));
+    }
+    *reinterpret_cast<bf16x4_bits*>(p.C + (int64_t)m * p.ldc + p.N + n) = du;
   }
   bf16x4_bits o;
 #pragma unroll
@@ -832,6 +850,13 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   if (a->bias) OVLA_REQUIRE((((uintptr_t)a->bias) & 7) == 0, "ovla_gemm_bf16: bias alignment");
   if (a->colscale) OVLA_REQUIRE((((uintptr_t)a->colscale) & 7) == 0, "ovla_gemm_bf16: colscale alignment");
   if (a->film_gamma) OVLA_REQUIRE(a->film_beta && a->film_rows > 0, "ovla_gemm_bf16: FiLM needs beta and film_rows");
+  if (a->dact_src) {
+    OVLA_REQUIRE(a->dact_mode == 1 || a->dact_mode == 2, "ovla_gemm_bf16: dact_mode %d (1 = activation derivative, 2 = SwiGLU)", a->dact_mode);
+    OVLA_REQUIRE((a->ld_dact % 4) == 0 && (((uintptr_t)a->dact_src) & 7) == 0, "ovla_gemm_bf16: dact_src alignment");
+    OVLA_REQUIRE(!a->bias && !a->residual && !a->colscale && !a->film_gamma && !a->C_pre && a->act == OVLA_ACT_NONE,
+                 "ovla_gemm_bf16: a backward epilogue excludes the forward ones");
+    if (a->dact_mode == 2) OVLA_REQUIRE(a->ldc >= 2 * (int64_t)a->N && a->ld_dact >= 2 * (int64_t)a->N, "ovla_gemm_bf16: SwiGLU backward writes/reads [M, 2N]");
+  }
   if (a->split_k > 1)
     OVLA_REQUIRE(a->workspace != nullptr && aligned16(a->workspace) && a->workspace_bytes >= ovla_gemm_workspace_bytes(a->M, a->N, a->split_k),
                  "ovla_gemm_bf16: split_k=%d needs a 16-byte aligned workspace of %lld bytes", a->split_k, (long long)ovla_gemm_workspace_bytes(a->M, a->N, a->split_k));
@@ -848,6 +873,7 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   p.k2_group_n = a->k2_group_n; p.a_group_n = a->a_group_n; p.act = a->act; p.split_k = a->split_k > 1 ? a->split_k : 1;
   p.ws = (float*)a->workspace;
   p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
+  p.dact_src = (const bf16_bits*)a->dact_src; p.ld_dact = a->ld_dact; p.dact_mode = a->dact_src ? a->dact_mode : 0; p.dact_act = a->dact_act;
   p.T1 = cdiv(p.K, BK); p.T2 = p.K2 > 0 ? cdiv(p.K2, BK) : 0;
   if (p.split_k > p.T1 + p.T2) p.split_k = p.T1 + p.T2;
   p.full_tiles = 0; p.rem_tiles = 0; p.rem_splits = 1;

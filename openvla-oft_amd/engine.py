@@ -27,6 +27,12 @@ from .config import VLAConfig, VitConfig
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+# Which activation derivatives ride in the data-gradient GEMM's epilogue (ovla.h "backward epilogues"): none | act | swiglu | all.
+# Bit-identical to the separate act_bwd / swiglu_bwd kernels and it saves the dh round trip, but measured on MI355X it is NOT faster
+# (B = 8: none 177.1-177.6 ms/step, act 177.5-178.0, swiglu 178.0, all 178.1-178.4): a 256x256 tile owns its CU, so the extra epilogue
+# traffic is exposed, while the separate elementwise kernels already run at the HBM roofline.  Default: separate kernels.
+_FUSE = os.environ.get("OVLA_FUSE_DACT", "none")
+_FUSE_ACT, _FUSE_SWIGLU = _FUSE in ("act", "all"), _FUSE in ("swiglu", "all")
 
 
 # ======================================================================================================================
@@ -194,8 +200,10 @@ class LoraLinear:
             y = ops.gemm(x, self.W, out=out, bias=self.bias, act=act, residual=residual, colscale=colscale, c_pre=c_pre, film=film)
         return y, (x, t_s)
 
-    def bwd(self, dy, saved, need_dx=True):
-        """dy [M, out] (gradient w.r.t. the pre-activation linear output) -> dx [M, in]; accumulates LoRA grads."""
+    def bwd(self, dy, saved, need_dx=True, dact=None):
+        """dy [M, out] (gradient w.r.t. the pre-activation linear output) -> dx [M, in]; accumulates LoRA grads.
+        `dact` = ("act", z, act_id) / ("swiglu", gu): the data-gradient GEMM's epilogue also applies the derivative of the
+        activation that PRODUCED this linear's input (returns dz / d(gate|up) instead of dx: ovla.h backward epilogues)."""
         x, t_s = saved
         dx = None
         if getattr(self, "merged", False):
@@ -209,9 +217,9 @@ class LoraLinear:
             probs.append((dt, x, self.A.grad))
             ops.gemm_tn_grouped(probs)
             if need_dx:
-                dx = ops.gemm(dy, self.WT, a2=dt, b2=self.AT)
+                dx = ops.gemm(dy, self.WT, a2=dt, b2=self.AT, dact=dact)
         elif need_dx:
-            dx = ops.gemm(dy, self.WT)
+            dx = ops.gemm(dy, self.WT, dact=dact)
         return dx
 
 
@@ -362,8 +370,10 @@ class VitTower:
             x, mean1, rstd1, s_qkv, qkv, o, lse, s_proj, x2, mean2, rstd2, s_fc1, z, s_fc2, fsv = sv
             # x3 = x2 + ls2 * fc2(act(fc1(ln2(x2))))
             d = ops.colscale(dx, blk["ls2"]) if blk["ls2"] is not None else dx
-            dh = blk["fc2"].bwd(d, s_fc2)
-            dz = ops.act_bwd(z, dh, self.act)
+            if _FUSE_ACT:
+                dz = blk["fc2"].bwd(d, s_fc2, dact=("act", z, self.act))  # dh * act'(z) in the dgrad GEMM's epilogue
+            else:
+                dz = ops.act_bwd(z, blk["fc2"].bwd(d, s_fc2), self.act)
             dh2 = blk["fc1"].bwd(dz, s_fc1)
             ops.norm_bwd(x2, dh2, blk["ln2_w"], mean2, rstd2, rms=False, dx=dx, dx_accum=True)       # dx now = d x2
             if fsv is not None:   # through the FiLM modulation: dgamma, dbeta, dx <- dx * (1 + gamma)
@@ -454,8 +464,10 @@ class LlamaStack:
         dx = ops.norm_bwd(x_last, dout, self.norm_w, None, rf, rms=True)
         for li, (l, sv) in enumerate(zip(reversed(self.layers), reversed(saved))):
             x, r1, s_qkv, qkv, o, lse, s_o, x2, r2, s_gu, gu, s_d = sv
-            dh = l["down"].bwd(dx, s_d)
-            dgu = ops.swiglu_bwd(gu, dh)
+            if _FUSE_SWIGLU:
+                dgu = l["down"].bwd(dx, s_d, dact=("swiglu", gu))        # SwiGLU' in the dgrad GEMM's epilogue: dh never hits HBM
+            else:
+                dgu = ops.swiglu_bwd(gu, l["down"].bwd(dx, s_d))
             dh2 = l["gu"].bwd(dgu, s_gu)
             ops.norm_bwd(x2, dh2, l["n2"], None, r2, rms=True, dx=dx, dx_accum=True)                   # dx = d x2
             do = l["o"].bwd(dx, s_o)
@@ -816,9 +828,13 @@ class VLAEngine:
         cfg = self.cfg
         tower_saved, s1, z1, s2, z2, s3, B, I = saved
         Np, vd = cfg.dino.n_patches, cfg.vision_dim
-        d = self.proj[2].bwd(dpatches, s3)
-        d = self.proj[1].bwd(ops.act_bwd(z2, d, ops.ACT_GELU), s2)
-        dfeat = self.proj[0].bwd(ops.act_bwd(z1, d, ops.ACT_GELU), s1)            # [B*I*Np, vd]
+        if _FUSE_ACT:
+            d = self.proj[2].bwd(dpatches, s3, dact=("act", z2, ops.ACT_GELU))    # d z2 = d h2 * gelu'(z2), in the dgrad epilogue
+            d = self.proj[1].bwd(d, s2, dact=("act", z1, ops.ACT_GELU))           # d z1
+        else:
+            d = ops.act_bwd(z2, self.proj[2].bwd(dpatches, s3), ops.ACT_GELU)
+            d = ops.act_bwd(z1, self.proj[1].bwd(d, s2), ops.ACT_GELU)
+        dfeat = self.proj[0].bwd(d, s1)                                           # [B*I*Np, vd]
         def run_tower(k, tower, col0):
             vc = tower.vc
             T = vc.n_patches + vc.n_prefix

@@ -68,7 +68,7 @@ def check_device(index: int = 0) -> None:
 
 # ----------------------------------------------------------------------------------------------------------------------
 def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=None, c_pre=None, a2=None, b2=None,
-         k2_group_n=0, film=None, split_k=1, tile=0, alpha=1.0, a_group_n=0):
+         k2_group_n=0, film=None, split_k=1, tile=0, alpha=1.0, a_group_n=0, dact=None):
     """out[M,N] = epilogue(a[M,K] @ b[N,K]^T (+ a2[M,G*K2] @ b2[N,K2]^T)); all bf16 2-D, last dim contiguous."""
     _chk(a, name="a"); _chk(b, name="b")
     M, K = a.shape
@@ -78,9 +78,10 @@ def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=Non
         assert a.shape[1] == (N // a_group_n) * K, f"gemm(block-diagonal): {a.shape} vs {b.shape}"
     assert b.shape[1] == K, f"gemm: K mismatch {a.shape} x {b.shape}"
     assert a.stride(1) == 1 and b.stride(1) == 1
+    out_cols = 2 * N if (dact is not None and dact[0] == "swiglu") else N
     if out is None:
-        out = torch.empty((M, N), dtype=BF16, device=a.device)
-    assert out.shape == (M, N) and out.stride(1) == 1
+        out = torch.empty((M, out_cols), dtype=BF16, device=a.device)
+    assert out.shape == (M, out_cols) and out.stride(1) == 1
     g = STRUCTS["ovla_gemm_args"]()
     g.A, g.lda, g.B, g.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
     g.C, g.ldc = out.data_ptr(), out.stride(0)
@@ -104,6 +105,11 @@ def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=Non
         gamma, beta, rows = film
         assert gamma.shape[-1] == N and gamma.is_contiguous() and beta.is_contiguous()
         g.film_gamma, g.film_beta, g.film_rows = gamma.data_ptr(), beta.data_ptr(), rows
+    if dact is not None:   # backward epilogue: ("act", z, act_id) or ("swiglu", gu)
+        src = dact[1]
+        assert src.stride(1) == 1 and src.shape == (M, out_cols) and src.dtype == BF16
+        g.dact_src, g.ld_dact = src.data_ptr(), src.stride(0)
+        g.dact_mode, g.dact_act = (2, ACT_SILU) if dact[0] == "swiglu" else (1, dact[2])
     g.M, g.N, g.K, g.act, g.split_k, g.tile, g.alpha, g.a_group_n = M, N, K, act, split_k, tile, alpha, a_group_n
     ws = _workspace(a.device, max(4 * split_k * M * N if split_k > 1 else 0, _WS_BYTES))
     g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4

@@ -528,3 +528,30 @@ def test_image_prep_bit_exact_vs_oracle(ops, dev, crop, hw):
         ref.append(vo.image_transform(q, (vo.IMAGENET_MEAN, vo.SIGLIP_MEAN), (vo.IMAGENET_STD, vo.SIGLIP_STD)))
     ref = torch.cat(ref, 0)[None].to(BF)
     assert torch.equal(got.cpu(), ref), f"{(got.cpu() != ref).sum().item()} of {ref.numel()} values differ"
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(4864, 1024, 4096, 0), (1000, 512, 256, 1), (300, 264, 1088, 101), (522, 1024, 4096, 0)])
+@pytest.mark.parametrize("act", [1, 2, 3])
+def test_gemm_backward_epilogue_act(ops, dev, M, N, K, tile, act):
+    """dact_mode 1: C = (A B^T + A2 B2^T) * act'(z) must equal the separate act_bwd kernel applied to the plain GEMM output, bit for bit."""
+    torch.manual_seed(M + act)
+    a, b = rnd(M, K, dev=dev, scale=0.3), rnd(N, K, dev=dev, scale=0.1)
+    t, lb = rnd(M, 32, dev=dev), rnd(N, 32, dev=dev, scale=0.2)
+    z = rnd(M, N, dev=dev)
+    dh = ops.gemm(a, b, a2=t, b2=lb, tile=tile)
+    ref = ops.act_bwd(z, dh, act)
+    got = ops.gemm(a, b, a2=t, b2=lb, tile=tile, dact=("act", z, act))
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("M,F,K,tile", [(4864, 1024, 512, 0), (608, 2752, 1024, 0), (200, 256, 320, 1), (2500, 1280, 2048, 117)])
+def test_gemm_backward_epilogue_swiglu(ops, dev, M, F, K, tile):
+    """dact_mode 2: the down-projection's data-gradient GEMM writes d(gate|up) [M, 2F] directly == swiglu_bwd(gu, dh) of the plain output."""
+    torch.manual_seed(M + F)
+    a, b = rnd(M, K, dev=dev, scale=0.3), rnd(F, K, dev=dev, scale=0.1)
+    t, lb = rnd(M, 32, dev=dev), rnd(F, 32, dev=dev, scale=0.2)
+    gu = rnd(M, 2 * F, dev=dev)
+    dh = ops.gemm(a, b, a2=t, b2=lb, tile=tile)
+    ref = ops.swiglu_bwd(gu, dh)
+    got = ops.gemm(a, b, a2=t, b2=lb, tile=tile, dact=("swiglu", gu))
+    assert got.shape == (M, 2 * F) and torch.equal(got, ref)
