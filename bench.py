@@ -355,7 +355,7 @@ def main():
         fwd_f, train_f = flops_per_sample(cfg, S, cfg.num_images)
         roofline["step_tflops_per_sample"] = train_f / 1e12
         roofline["step_mfma_frac"] = (train_f * args.batch / (ms_per_step * 1e-3)) / 1e12 / PEAK_BF16_TFLOPS
-        if not args.no_cpu_baseline and not args.tiny:
+        if not args.no_cpu_baseline and not args.tiny and world == 1:   # the CPU baseline is reported at N = 1 only
             cpu = cpu_baseline(cfg, S, train_f)
     # ---- BASELINE.json configs[1]: single-chunk inference, batch 1; rank 0 only, no collectives.  Runs LAST on the training
     # engine: (1) adapters applied on the fly (the state during fine-tuning evaluation), (2) adapters merged into the base
