@@ -1,0 +1,105 @@
+"""The HIP path against the COMMITTED fixtures of tests/golden/ (no oracle computation at test time except where noted):
+G6 full forward, G8 LoRA linear (plain-torch autograd numbers), G9 torch.optim.AdamW on bf16 parameters, G11 config-1 plumbing."""
+import importlib
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vla_oracle as vo
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+G = Path(__file__).resolve().parent / "golden"
+load = importlib.import_module
+
+
+def fixture(name):
+    return dict(np.load(G / name, allow_pickle=False))
+
+
+def tiny_engine(dev, head="l1"):
+    engine_mod, weights_mod, config_mod = load("openvla-oft_amd.engine"), load("openvla-oft_amd.weights"), load("openvla-oft_amd.config")
+    ocfg = vo.tiny_config()
+    sd = vo.random_state_dict(ocfg, seed=0)
+    cfg = config_mod.VLAConfig.from_any(ocfg)
+    get, has = weights_mod.make_getter(sd, dev)
+    return engine_mod.VLAEngine(cfg, get, dev, lora=True, use_proprio=True, head=head, has=has), cfg, ocfg, sd
+
+
+def test_g6_full_forward_fixture(dev):
+    """fp32 fixture vs bf16 HIP path: tolerance = what bf16 weights + activations cost on this model (the live comparison against
+    the bf16-emulating oracle with the tight bound is test_engine_gpu.py)."""
+    g = fixture("g6_full_forward.npz")
+    eng, cfg, _, _ = tiny_engine(dev)
+    b = {k: torch.from_numpy(g[k]) for k in ("input_ids", "attention_mask", "labels", "pixel_values", "proprio", "actions")}
+    out = eng.forward(b["input_ids"], b["attention_mask"], b["pixel_values"], b["labels"], proprio=b["proprio"], train=False)
+    assert out["P"] == int(g["P"])
+    ah, _ = eng.gather_action_hidden(out["hidden"], out["action_rows"])
+    ref = torch.from_numpy(g["action_hidden"])
+    err = ((ah.float().cpu().view_as(ref) - ref).abs().max() / ref.abs().max()).item()
+    pred, loss_sum, _ = eng.head.fwd(ah, target=b["actions"].to(dev, BF).reshape(-1, 7).contiguous())
+    perr = np.abs(pred.float().cpu().numpy().reshape(g["pred"].shape) - g["pred"]).max()
+    print(f"G6: action hidden rel err {err:.3e}, pred Linf {perr:.3e}, loss {loss_sum.item() / pred.numel():.5f} vs {float(g['loss']):.5f}")
+    assert err < 4e-2 and perr < 6e-2 and abs(loss_sum.item() / pred.numel() - float(g["loss"])) < 3e-2
+
+
+def test_g8_lora_linear_fixture(dev):
+    """engine.LoraLinear (K-extended GEMM forward, block GEMMs + TN GEMMs backward) vs plain-torch autograd numbers."""
+    g = fixture("g8_lora_linear.npz")
+    engine_mod = load("openvla-oft_amd.engine")
+    t = lambda k: torch.from_numpy(g[k]).to(dev)  # noqa: E731
+    # pad the 6 rows to 8 (GEMM M granularity) with zeros: zero rows contribute nothing to any gradient
+    x = torch.zeros(8, 48, device=dev); x[:6] = t("x")
+    dy = torch.zeros(8, 40, device=dev); dy[:6] = t("dy")
+    store = engine_mod.ParamStore(dev)
+    lin = engine_mod.LoraLinear(store, "l", t("W").to(BF), t("bias").to(BF), t("A").to(BF), t("B").to(BF), 1, float(g["scale"]))
+    store.finalize(); lin.refresh_derived(); store.zero_grad()
+    y, saved = lin.fwd(x.to(BF).contiguous())
+    dx = lin.bwd(dy.to(BF).contiguous(), saved)
+    torch.cuda.synchronize()
+    close = lambda a, ref, tol: np.abs(a.float().cpu().numpy() - ref).max() <= tol * max(1.0, np.abs(ref).max())  # noqa: E731
+    assert close(y[:6], g["y"], 2e-2) and close(dx[:6], g["dx"], 2e-2)
+    assert close(lin.A.grad, g["dA"], 2e-2) and close(lin.B.grad, g["dB"], 2e-2)
+
+
+def test_g9_adamw_fixture(dev):
+    """ovla_adamw on bf16 parameters vs three recorded torch.optim.AdamW steps (lr 5e-4, betas (0.9, 0.999), eps 1e-8, wd 0.01)."""
+    g = fixture("g9_adamw_bf16.npz")
+    ops = load("openvla-oft_amd.ops")
+    p = torch.from_numpy(g["p0"]).to(dev, BF)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(3):
+        grad = torch.from_numpy(g["grads"][step]).to(dev)      # fp32 accumulator holding bf16-exact values
+        ops.adamw(p, m, v, grad, step=step + 1, lr=float(g["lr"]), beta1=float(g["betas"][0]), beta2=float(g["betas"][1]), eps=float(g["eps"]),
+                  weight_decay=float(g["weight_decay"]))
+        ref = torch.from_numpy(g["after"][step])
+        got = p.float().cpu()
+        ulp = (got - ref).abs() / (ref.abs().clamp_min(1e-9) * 2.0 ** -7)
+        assert (got != ref).float().mean().item() < 5e-3 and ulp.max().item() <= 1.01, f"step {step}: {(got != ref).sum().item()} differ"
+
+
+def test_g11_config1_plumbing_fixture(dev):
+    """The observation of the fixture through the DEVICE image path (ovla_image_prep) and the tiny model: crops bit-identical to the
+    recorded uint8 crops, actions within bf16 tolerance of the recorded fp32 actions."""
+    g = fixture("g11_config1_plumbing.npz")
+    ops, modeling, config_mod = load("openvla-oft_amd.ops"), load("openvla-oft_amd.modeling"), load("openvla-oft_amd.config")
+    frames = torch.from_numpy(np.stack([g["full_image"], g["wrist_image"]])).to(dev)
+    pv = ops.image_prep(frames, crop=True)
+    ref_pv = torch.cat([vo.image_transform(g[k], (vo.IMAGENET_MEAN, vo.SIGLIP_MEAN), (vo.IMAGENET_STD, vo.SIGLIP_STD)) for k in ("crop_full", "crop_wrist")], 0)[None]
+    assert torch.equal(pv.cpu(), ref_pv.to(BF)), "device crop + normalise == recorded crops through the host transform"
+    ocfg = vo.tiny_config()
+    sd = vo.random_state_dict(ocfg, seed=0)
+    cfg = config_mod.VLAConfig.from_any(ocfg)
+    stats = {"t": {"action": {"q01": [-1.0] * 7, "q99": [1.0] * 7, "mask": [True] * 6 + [False]}}}
+    vla = modeling.OpenVLAForActionPrediction(cfg, sd, device=dev, norm_stats=stats)
+    sub = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}  # noqa: E731
+    head = modeling.L1RegressionActionHead(cfg.llm_dim, cfg.llm_dim, 7, device=dev, state_dict=sub("action_head."))
+    pp = modeling.ProprioProjector(cfg.llm_dim, 8, device=dev, state_dict=sub("proprio_projector."))
+    ids = torch.from_numpy(g["input_ids"])
+    act, _ = vla.predict_action(input_ids=ids, unnorm_key="t", proprio=g["proprio_normalized"], proprio_projector=pp, action_head=head,
+                                pixel_values=pv[:, :, ::4, ::4].contiguous(), attention_mask=torch.ones_like(ids, dtype=torch.bool))
+    err = np.abs(act - g["actions"]).max()
+    print(f"G11: actions Linf vs recorded fp32 actions {err:.3e}")
+    assert act.shape == (8, 7) and err < 6e-2

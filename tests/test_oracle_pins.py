@@ -128,3 +128,74 @@ def test_g10_collator_layout():
     batch = synth.collate(inst, pad_token_id=32000)
     for k in ("input_ids", "labels", "attention_mask", "pixel_values", "actions", "proprio"):
         assert np.array_equal(batch[k].numpy(), g["batch." + k]), k
+
+
+# ---- fixtures whose source of truth is plain torch or the oracle at the time of writing (tests/golden/make_golden_own.py) ----------
+def _tiny():
+    ocfg = vo.tiny_config()
+    sd = vo.random_state_dict(ocfg, seed=0)
+    return ocfg, sd, sum(float(v.double().abs().sum()) for v in sd.values())
+
+
+def test_g6_full_forward_regression():
+    """assemble -> LLM -> shift-by-one gather -> L1 head + loss on a ragged collator-shaped batch: the oracle still produces the
+    numbers it produced when the fixture was written (its pieces are pinned to the reference by G1-G5, G10)."""
+    g = load("g6_full_forward.npz")
+    ocfg, sd, chk = _tiny()
+    assert chk == pytest.approx(float(g["sd_checksum"]), rel=1e-12), "seeded weights changed: regenerate the fixture deliberately"
+    b = {k: torch.from_numpy(g[k]) for k in ("input_ids", "attention_mask", "labels", "pixel_values", "proprio", "actions")}
+    o = vo.Oracle(ocfg, sd, mode="fp32")
+    with torch.no_grad():
+        hidden, P = o.multimodal_hidden(b["input_ids"], b["attention_mask"], b["pixel_values"], b["labels"], b["proprio"])
+        loss, pred, ah = o.train_forward(b)
+    assert P == int(g["P"]) == 2 * 16 + 1
+    assert np.allclose(hidden[0, : g["hidden_valid_row0"].shape[0]].numpy(), g["hidden_valid_row0"], atol=1e-5, rtol=1e-5)
+    assert np.allclose(ah.numpy(), g["action_hidden"], atol=1e-5, rtol=1e-5) and np.allclose(pred.numpy(), g["pred"], atol=1e-5)
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-6)
+    # the shift-by-one gather: hidden at (token position - 1) of the 56 action slots of row 0 (prompt length 9)
+    assert np.allclose(ah[0].numpy(), hidden[0, 1 + P + 9 - 2: 1 + P + 9 - 2 + 56].numpy())
+
+
+def test_g7_vit_blocks_regression():
+    g = load("g7_vit_blocks.npz")
+    ocfg, sd, chk = _tiny()
+    assert chk == pytest.approx(float(g["sd_checksum"]), rel=1e-12)
+    o = vo.Oracle(ocfg, sd, mode="fp32")
+    img = torch.from_numpy(g["img"])
+    with torch.no_grad():
+        assert np.allclose(o.vit(img, "vision_backbone.featurizer.", ocfg.dino).numpy(), g["dino"], atol=1e-5, rtol=1e-5)
+        assert np.allclose(o.vit(img, "vision_backbone.fused_featurizer.", ocfg.siglip).numpy(), g["siglip"], atol=1e-5, rtol=1e-5)
+    assert g["dino"].shape == (3, 16, 128) and g["siglip"].shape == (3, 16, 144), "prefix tokens dropped, second-to-last block"
+
+
+def test_g8_lora_linear_matches_plain_torch():
+    g = load("g8_lora_linear.npz")
+    cfg = vo.tiny_config(lora_rank=8, lora_alpha=4)
+    assert cfg.lora_scale == float(g["scale"])
+    sd = {"l.weight": torch.from_numpy(g["W"]), "l.bias": torch.from_numpy(g["bias"]),
+          "l.lora_A.weight": torch.from_numpy(g["A"]).requires_grad_(True), "l.lora_B.weight": torch.from_numpy(g["B"]).requires_grad_(True)}
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = vo.Oracle(cfg, sd).linear(x, "l")
+    y.backward(torch.from_numpy(g["dy"]))
+    assert np.allclose(y.detach().numpy(), g["y"], atol=1e-6)
+    assert np.allclose(x.grad.numpy(), g["dx"], atol=1e-6) and np.allclose(sd["l.lora_A.weight"].grad.numpy(), g["dA"], atol=1e-6)
+    assert np.allclose(sd["l.lora_B.weight"].grad.numpy(), g["dB"], atol=1e-6)
+
+
+def test_g11_config1_plumbing_regression():
+    """BASELINE.json configs[0] plumbing on a synthetic observation of the reference pickle's shapes: center crop -> 6*I-channel
+    tensor -> tiny fp32 model -> 8 unnormalised actions."""
+    g = load("g11_config1_plumbing.npz")
+    ocfg, sd, chk = _tiny()
+    assert chk == pytest.approx(float(g["sd_checksum"]), rel=1e-12)
+    crops = [vo.crop_and_resize_center(g[k]) for k in ("full_image", "wrist_image")]
+    assert np.array_equal(crops[0], g["crop_full"]) and np.array_equal(crops[1], g["crop_wrist"])
+    pv = torch.cat([vo.image_transform(c, (vo.IMAGENET_MEAN, vo.SIGLIP_MEAN), (vo.IMAGENET_STD, vo.SIGLIP_STD)) for c in crops], 0)[None]
+    assert pv.shape == (1, 12, 224, 224) and pv.double().sum().item() == pytest.approx(float(g["pixel_values_sum"]), rel=1e-9)
+    assert np.allclose(pv[0, :, 100, 50:54].numpy(), g["pixel_values_probe"])
+    prop = vo.normalize_proprio(g["state"], {"q01": [-2.0] * 8, "q99": [2.0] * 8}, ocfg.norm_type)
+    assert np.allclose(prop, g["proprio_normalized"])
+    ids = torch.from_numpy(g["input_ids"])
+    actions, _ = vo.Oracle(ocfg, sd).predict_action(ids, torch.ones_like(ids, dtype=torch.bool), pv[:, :, ::4, ::4].contiguous(), proprio=prop,
+                                                    unnorm_stats={"q01": [-1.0] * 7, "q99": [1.0] * 7, "mask": [True] * 6 + [False]})
+    assert np.asarray(actions).shape == (8, 7) and np.allclose(actions, g["actions"], atol=1e-5)
