@@ -217,3 +217,40 @@ def test_resume_continues_the_same_trajectory(world, tmp_path, dev):
                 model_config=world["cfg"], state_dict={k: v.clone() for k, v in world["sd"].items()}, log=lines.append,
                 dataset=(world["synth"].make_batch(2, seed=200 + s, prompt_lens=[9, 8], image_size=56) for s in range(10)))
     assert any("resumed step 3" in str(l) and "optimizer state: True" in str(l) for l in lines), lines[:4]
+
+
+def test_deploy_server_act_endpoint(world):
+    """vla-scripts/deploy.py mirror: POST /act with a json_numpy-style payload -> action chunk, equal to calling get_vla_action
+    directly; the double-encoded form and the "error" answer to a malformed request behave like the reference."""
+    import json
+
+    from fastapi.testclient import TestClient
+
+    dep, utils = load("openvla-oft_amd.vla_scripts.deploy"), load("openvla-oft_amd.experiments.robot.openvla_utils")
+    rng = np.random.default_rng(1)
+    obs = {"full_image": rng.integers(0, 256, (224, 224, 3), dtype=np.uint8), "wrist_image": rng.integers(0, 256, (224, 224, 3), dtype=np.uint8),
+           "state": rng.uniform(-1, 1, 8), "instruction": "pick up the black bowl"}
+    cfg = dep.DeployConfig(num_images_in_input=2, use_proprio=True, center_crop=True, unnorm_key="libero_spatial_no_noops", num_open_loop_steps=8)
+
+    class P56(utils.PrismaticProcessor):       # the tiny test towers take 56 x 56 inputs
+        def __call__(self, text, image):
+            out = super().__call__(text, image)
+            out["pixel_values"] = out["pixel_values"][:, :, ::4, ::4].contiguous()
+            return out
+
+    tok = lambda text: [1] + [3 + (ord(c) % 200) for c in text][:20]  # noqa: E731
+    server = dep.OpenVLAServer(cfg, vla=world["vla"], processor=P56(tok), action_head=world["head"], proprio_projector=world["pp"])
+    try:
+        client = TestClient(server.build_app())
+        r = client.post("/act", json=dep._encode(obs))
+        assert r.status_code == 200
+        acts = dep._decode(r.json())
+        direct = utils.get_vla_action(cfg, world["vla"], P56(tok), {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in obs.items()},
+                                      obs["instruction"], action_head=world["head"], proprio_projector=world["pp"])
+        assert len(acts) == 8 and all(np.array_equal(a, b) for a, b in zip(acts, direct)), "server == direct call (graph replay == eager)"
+        r2 = client.post("/act", json={"encoded": json.dumps(dep._encode(obs))})
+        acts2 = dep._decode(json.loads(r2.json()))
+        assert all(np.array_equal(a, b) for a, b in zip(acts2, direct))
+        assert client.post("/act", json={"instruction": "no images"}).json() == "error"
+    finally:
+        world["vla"].enable_graph_replay(False)

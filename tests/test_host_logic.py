@@ -185,3 +185,19 @@ def test_gemm_schedule_decisions():
     assert plan(4864, 4096, 4096, 32)[1:4] == (256, 48, 5)
     # more work never gets cheaper
     assert plan(4864, 8192, 4096)[4] > plan(4864, 4096, 4096)[4] and plan(4864, 4096, 8192)[4] > plan(4864, 4096, 4096)[4]
+
+
+def test_deploy_wire_codec_roundtrip():
+    """json_numpy-style wire format of the /act endpoint (deploy.py:80-95), incl. the "encoded" double encoding."""
+    import json
+
+    d = importlib.import_module("openvla-oft_amd.vla_scripts.deploy")
+    obs = {"full_image": np.arange(24, dtype=np.uint8).reshape(2, 4, 3), "state": np.linspace(-1, 1, 8), "instruction": "pick up the bowl"}
+    wire = json.loads(json.dumps(d._encode(obs)))
+    back, double = d.decode_payload(wire)
+    assert not double and back["instruction"] == obs["instruction"]
+    assert back["full_image"].dtype == np.uint8 and np.array_equal(back["full_image"], obs["full_image"]) and np.array_equal(back["state"], obs["state"])
+    back2, double2 = d.decode_payload({"encoded": json.dumps(d._encode(obs))})
+    assert double2 and np.array_equal(back2["full_image"], obs["full_image"])
+    with pytest.raises(AssertionError, match="Only uses encoded payload"):
+        d.decode_payload({"encoded": "{}", "x": 1})
