@@ -154,6 +154,8 @@ typedef struct {
   int32_t B, H, S, head_dim;
   int32_t causal;
   float scale;
+  const void* rope_cos;    /* optional bf16 [S, head_dim/2] tables (ovla_rope_table): dQ and dK are written with the INVERSE RoPE rotation */
+  const void* rope_sin;    /* applied (the gradient w.r.t. the pre-RoPE q / k: saves the separate ovla_rope(inverse) pass); head_dim 128 */
 } ovla_attn_bwd_args;
 int ovla_attn_bwd(const ovla_attn_bwd_args* a, void* stream);
 

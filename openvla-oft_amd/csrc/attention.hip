@@ -35,6 +35,7 @@ struct AttnParams {
   const int32_t* kv_len;
   int B, H, S, hd, causal;
   float scale;
+  const bf16_bits *rope_cos, *rope_sin;   // optional: inverse RoPE fused into the dQ / dK epilogues
 };
 
 OVLA_DEV bf16x4_bits lds_tr16(const bf16_bits* p) {
@@ -271,6 +272,31 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // dQ: one workgroup per 64-query block, loops over K/V tiles.
+// Inverse RoPE (HF rotate_half convention) on one row's gradient held as DT = hd/16 accumulator tiles: lane (row = lane & 15,
+// g = lane >> 4) owns columns 16 d + 4 g + j; the rotation partner of column c is c +- hd/2 = tile d +- DT/2, same lane.  Values are
+// first rounded to bf16 (what the separate pass would read back), then rotated with rope_kernel's arithmetic (inverse = 1).
+template <int DT>
+OVLA_DEV void inverse_rope_store(const f32x4 (&acc)[DT], float scale, bf16_bits* dst, int hd, int pos, int g, const bf16_bits* cosT, const bf16_bits* sinT) {
+  constexpr int HT = DT / 2;
+  const int half = hd >> 1;
+#pragma unroll
+  for (int d = 0; d < HT; ++d) {
+    const int col = d * 16 + 4 * g;
+    const bf16x4_bits cs = *reinterpret_cast<const bf16x4_bits*>(cosT + (int64_t)pos * half + col);
+    const bf16x4_bits sn = *reinterpret_cast<const bf16x4_bits*>(sinT + (int64_t)pos * half + col);
+    bf16x4_bits olo, ohi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = bfround(acc[d][j] * scale), b = bfround(acc[d + HT][j] * scale);
+      const float cc = bf2f((bf16_bits)cs[j]), s = -bf2f((bf16_bits)sn[j]);
+      olo[j] = (short)f2bf(bfround(a * cc) + bfround(-b * s));
+      ohi[j] = (short)f2bf(bfround(b * cc) + bfround(a * s));
+    }
+    *reinterpret_cast<bf16x4_bits*>(dst + col) = olo;
+    *reinterpret_cast<bf16x4_bits*>(dst + half + col) = ohi;
+  }
+}
+
 template <int DP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   constexpr int KS = DP / 32, DT = DP / 16, STRIDE = DP + 16;
@@ -357,18 +383,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   }
   if (qrow < p.S) {
     bf16_bits* dQb = p.dQ + ((int64_t)b * p.S + qrow) * p.dq_stride + (int64_t)h * p.hd;
+    if (p.rope_cos) {
+      inverse_rope_store<DT>(accQ, p.scale, dQb, p.hd, qrow, g, p.rope_cos, p.rope_sin);
+    } else {
 #pragma unroll
-    for (int d = 0; d < DT; ++d) {
-      const int col = d * 16 + 4 * g;
-      if (col < p.hd) {
-        bf16x4_bits o;
+      for (int d = 0; d < DT; ++d) {
+        const int col = d * 16 + 4 * g;
+        if (col < p.hd) {
+          bf16x4_bits o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = f2bf_s(accQ[d][j] * p.scale);
-        *reinterpret_cast<bf16x4_bits*>(dQb + col) = o;
+          for (int j = 0; j < 4; ++j) o[j] = f2bf_s(accQ[d][j] * p.scale);
+          *reinterpret_cast<bf16x4_bits*>(dQb + col) = o;
+        }
       }
     }
   }
 }
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // dK / dV: one workgroup per 64-key block (wave = 16 keys, key on the lane), loops over Q / dO tiles.
@@ -483,6 +514,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
   if (krow < p.S) {
     bf16_bits* dKb = p.dK + ((int64_t)b * p.S + krow) * p.dk_stride + (int64_t)h * p.hd;
     bf16_bits* dVb = p.dV + ((int64_t)b * p.S + krow) * p.dv_stride + (int64_t)h * p.hd;
+    if (p.rope_cos) inverse_rope_store<DT>(accK, p.scale, dKb, p.hd, krow, g, p.rope_cos, p.rope_sin);
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
       const int col = d * 16 + 4 * g;
@@ -493,7 +525,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
           ok_[j] = f2bf_s(accK[d][j] * p.scale);
           ov_[j] = f2bf_s(accV[d][j]);
         }
-        *reinterpret_cast<bf16x4_bits*>(dKb + col) = ok_;
+        if (!p.rope_cos) *reinterpret_cast<bf16x4_bits*>(dKb + col) = ok_;
         *reinterpret_cast<bf16x4_bits*>(dVb + col) = ov_;
       }
     }
@@ -554,6 +586,9 @@ extern "C" int ovla_attn_bwd(const ovla_attn_bwd_args* a, void* stream_) {
                    (a->dq_stride % 4) == 0 && (a->dk_stride % 4) == 0 && (a->dv_stride % 4) == 0,
                "ovla_attn_bwd: row strides must be multiples of 8 elements");
   OVLA_REQUIRE(aligned16(a->Q) && aligned16(a->K) && aligned16(a->V) && aligned16(a->O) && aligned16(a->dO), "ovla_attn_bwd: alignment");
+  if (a->rope_cos || a->rope_sin)
+    OVLA_REQUIRE(a->rope_cos && a->rope_sin && (a->head_dim == 128 || a->head_dim == 64) && (((uintptr_t)a->rope_cos | (uintptr_t)a->rope_sin) & 7) == 0,
+                 "ovla_attn_bwd: fused inverse RoPE needs both tables (8-byte aligned) and head_dim 64 or 128");
   AttnParams p = {};
   p.Q = (const bf16_bits*)a->Q; p.K = (const bf16_bits*)a->K; p.V = (const bf16_bits*)a->V; p.O = (const bf16_bits*)a->O;
   p.dO = (const bf16_bits*)a->dO; p.dQ = (bf16_bits*)a->dQ; p.dK = (bf16_bits*)a->dK; p.dV = (bf16_bits*)a->dV;
@@ -561,6 +596,7 @@ extern "C" int ovla_attn_bwd(const ovla_attn_bwd_args* a, void* stream_) {
   p.dq_stride = a->dq_stride; p.dk_stride = a->dk_stride; p.dv_stride = a->dv_stride;
   p.lse_in = a->lse; p.delta = a->delta; p.kv_len = a->kv_len;
   p.B = a->B; p.H = a->H; p.S = a->S; p.hd = a->head_dim; p.causal = a->causal; p.scale = a->scale;
+  p.rope_cos = (const bf16_bits*)a->rope_cos; p.rope_sin = (const bf16_bits*)a->rope_sin;
   const int64_t items = (int64_t)a->B * a->S * a->H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(items, 16)), dim3(256), 0, stream, p);
   OVLA_CHECK_LAUNCH("ovla_attn_bwd(delta)");

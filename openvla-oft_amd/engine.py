@@ -472,9 +472,9 @@ class LlamaStack:
             ops.norm_bwd(x2, dh2, l["n2"], None, r2, rms=True, dx=dx, dx_accum=True)                   # dx = d x2
             do = l["o"].bwd(dx, s_o)
             dqkv = torch.empty_like(qkv)
+            # dq / dk leave the attention backward already rotated back (inverse RoPE in its epilogues: no separate pass)
             ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, do, lse, B, S, H, hd, kv_len=kv_len, causal=causal,
-                         dq=dqkv[:, :D], dk=dqkv[:, D:2 * D], dv=dqkv[:, 2 * D:])
-            ops.rope_(dqkv, S, 2 * H, hd, self.cos, self.sin, inverse=True)
+                         dq=dqkv[:, :D], dk=dqkv[:, D:2 * D], dv=dqkv[:, 2 * D:], rope=(self.cos, self.sin))
             dh1 = l["qkv"].bwd(dqkv, s_qkv)
             ops.norm_bwd(x, dh1, l["n1"], None, r1, rms=True, dx=dx, dx_accum=True)                    # dx = d x
             if self.on_grads_ready is not None:   # this layer's LoRA gradients are final: the reducer may ship them

@@ -235,7 +235,8 @@ def attn_fwd(q, k, v, B, S, H, hd, *, kv_len=None, causal=False, scale=None, out
     return out, lse
 
 
-def attn_bwd(q, k, v, o, do, lse, B, S, H, hd, *, kv_len=None, causal=False, scale=None, dq=None, dk=None, dv=None):
+def attn_bwd(q, k, v, o, do, lse, B, S, H, hd, *, kv_len=None, causal=False, scale=None, dq=None, dk=None, dv=None, rope=None):
+    """`rope=(cos, sin)` (ovla_rope_table): dq / dk come out with the inverse RoPE rotation applied (gradients w.r.t. the pre-RoPE q / k)."""
     for t in (q, k, v, o, do):
         _chk(t)
         assert t.stride(1) == 1
@@ -255,6 +256,9 @@ def attn_bwd(q, k, v, o, do, lse, B, S, H, hd, *, kv_len=None, causal=False, sca
     g.kv_len = _p(kv_len)
     g.B, g.H, g.S, g.head_dim, g.causal = B, H, S, hd, int(causal)
     g.scale = float(scale if scale is not None else hd ** -0.5)
+    if rope is not None:
+        assert rope[0].shape[0] >= S and rope[0].shape[1] == hd // 2 and rope[0].is_contiguous() and rope[1].is_contiguous()
+        g.rope_cos, g.rope_sin = rope[0].data_ptr(), rope[1].data_ptr()
     e0 = _prof_begin()
     _lib.call("ovla_attn_bwd", g, _stream())
     _prof_end(e0, "attn_bwd", 10.0 * B * H * S * S * hd * (0.5 if causal else 1.0))

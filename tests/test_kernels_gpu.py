@@ -555,3 +555,24 @@ def test_gemm_backward_epilogue_swiglu(ops, dev, M, F, K, tile):
     ref = ops.swiglu_bwd(gu, dh)
     got = ops.gemm(a, b, a2=t, b2=lb, tile=tile, dact=("swiglu", gu))
     assert got.shape == (M, 2 * F) and torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("hd,S,causal", [(128, 608, False), (128, 200, True), (64, 130, False)])
+def test_attn_bwd_fused_inverse_rope(ops, dev, hd, S, causal):
+    """ovla_attn_bwd with rope tables == ovla_attn_bwd followed by ovla_rope(inverse) on dq | dk, bit for bit."""
+    torch.manual_seed(hd + S)
+    B, H = 2, 3
+    D = H * hd
+    qkv = rnd(B * S, 3 * D, dev=dev)
+    do = rnd(B * S, D, dev=dev, scale=0.1)
+    kv_len = torch.tensor([S, S - 37], dtype=torch.int32, device=dev)
+    cos, sin = ops.rope_table(S + 5, hd, 10000.0, dev)      # tables may be longer than the sequence
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    o, lse = ops.attn_fwd(q, k, v, B, S, H, hd, kv_len=kv_len, causal=causal)
+    d_ref = torch.empty_like(qkv)
+    ops.attn_bwd(q, k, v, o, do, lse, B, S, H, hd, kv_len=kv_len, causal=causal, dq=d_ref[:, :D], dk=d_ref[:, D:2 * D], dv=d_ref[:, 2 * D:])
+    ops.rope_(d_ref, S, 2 * H, hd, cos, sin, inverse=True)
+    d_fused = torch.empty_like(qkv)
+    ops.attn_bwd(q, k, v, o, do, lse, B, S, H, hd, kv_len=kv_len, causal=causal, dq=d_fused[:, :D], dk=d_fused[:, D:2 * D], dv=d_fused[:, 2 * D:],
+                 rope=(cos, sin))
+    assert torch.equal(d_fused, d_ref)
