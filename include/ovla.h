@@ -86,6 +86,10 @@ typedef struct {
   float alpha;                   /* scales the accumulator (LoRA alpha/r); 0 means 1 */
   const void* dact_src; int64_t ld_dact;   /* optional saved pre-activations for the backward epilogues above */
   int32_t dact_mode, dact_act;
+  const void* rope_cos; const void* rope_sin;  /* optional bf16 [>= rope_S, 64] tables: RoPE (head_dim 128, HF rotate_half, position = */
+  int32_t rope_S, rope_cols;                   /* row % rope_S) applied to output columns [0, rope_cols) -- the q | k heads of a fused
+                                                  q|k|v projection (modeling_llama apply_rotary_pos_emb).  Excludes the other epilogues;
+                                                  fused into the 256x256 config's epilogue, otherwise one extra ovla_rope launch. */
   void* workspace;               /* fp32 scratch: [split_k, M, N] when split_k > 1; also enables the auto schedules */
   int64_t workspace_bytes;       /* (hybrid remainder split, skinny-N split-K) when tile == 0; may be NULL/0 */
 } ovla_gemm_args;

@@ -40,6 +40,7 @@ struct GemmParams {
   int tiles_m, tiles_n, T1, T2;
   int fast_addr;  // 1: every staged byte offset fits in 32 bits (host-checked)
   const bf16_bits* dact_src; int64_t ld_dact; int dact_mode, dact_act;   // backward epilogues (ovla.h)
+  const bf16_bits *rope_cos, *rope_sin; int rope_S, rope_cols;           // forward RoPE on columns [0, rope_cols), head_dim 128
   int dbg;  // timing ablations (tools/gemm_ablate.py): bit0 = stage only the first two K tiles, bit1 = read fragments once, bit2 = every workgroup stages tile (0,0): all L2 hits
   int full_tiles, rem_tiles, rem_splits;  // hybrid schedule: tiles >= full_tiles are split rem_splits ways along K
 };
@@ -171,6 +172,25 @@ OVLA_DEV void epilogue_store(const GemmParams& p, int m, int n, f32x4 v) {
   bf16x4_bits o;
 #pragma unroll
   for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(v[j]);
+  *reinterpret_cast<bf16x4_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
+}
+
+// RoPE epilogue (head_dim 128): v = this lane's 4 accumulator sums at columns n..n+3 of row m, vp = the sums at the rotation
+// partner columns n +- 64 (same head).  y = bf16(acc) is the q|k projection output the reference rotates; arithmetic and rounding
+// points are rope_kernel's (elementwise.hip): lo' = bf16(a c) + bf16(-b s), hi' = bf16(b c) + bf16(a s).
+OVLA_DEV void rope_store(const GemmParams& p, int m, int n, f32x4 v, f32x4 vp) {
+  const int c = n & 127;                  // column within the head
+  const bool lo = c < 64;
+  const int pos = m % p.rope_S;
+  const bf16x4_bits cs = *reinterpret_cast<const bf16x4_bits*>(p.rope_cos + (int64_t)pos * 64 + (c & 63));
+  const bf16x4_bits sn = *reinterpret_cast<const bf16x4_bits*>(p.rope_sin + (int64_t)pos * 64 + (c & 63));
+  bf16x4_bits o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x = bfround(v[j]), y = bfround(vp[j]);
+    const float cc = bf2f((bf16_bits)cs[j]), sv = bf2f((bf16_bits)sn[j]);
+    o[j] = (short)f2bf(lo ? bfround(x * cc) + bfround(-y * sv) : bfround(x * cc) + bfround(y * sv));
+  }
   *reinterpret_cast<bf16x4_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
 }
 
@@ -403,6 +423,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
       const f32x4 v = *reinterpret_cast<const f32x4*>(wstage + row * LDSW + c4 * 4);
       const int m = m0 + wm * WTM + round * RM * 16 + row;
       const int n = n0 + wn * WTN + c4 * 4;
+      if constexpr (WTN == 128) {   // one wave slab = one 128-wide head: the rotation partner quad is 16 quads away in the same slab row
+        if (p.rope_cos && n < p.rope_cols) {
+          const f32x4 vp = *reinterpret_cast<const f32x4*>(wstage + row * LDSW + (c4 ^ 16) * 4);
+          if (m < p.M) rope_store(p, m, n, v, vp);
+          continue;
+        }
+      }
       if (m < p.M && n < p.N) epilogue_store(p, m, n, v);
     }
   }
@@ -655,6 +682,12 @@ __global__ __launch_bounds__(256) void gemm_hybrid_reduce_kernel(const GemmParam
     if (m >= p.M || n >= p.N) continue;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     for (int sidx = 0; sidx < p.rem_splits; ++sidx) v += *reinterpret_cast<const f32x4*>(slab0 + (int64_t)sidx * (BM * BN) + lm * BN + ln);
+    if (p.rope_cos && n < p.rope_cols) {   // BN is a multiple of 128 here (launch_cfg checks): the partner quad is in the same tile
+      f32x4 vp = {0.f, 0.f, 0.f, 0.f};
+      for (int sidx = 0; sidx < p.rem_splits; ++sidx) vp += *reinterpret_cast<const f32x4*>(slab0 + (int64_t)sidx * (BM * BN) + lm * BN + (ln ^ 64));
+      rope_store(p, m, n, v, vp);
+      continue;
+    }
     epilogue_store(p, m, n, v);
   }
 }
@@ -850,6 +883,14 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   if (a->bias) OVLA_REQUIRE((((uintptr_t)a->bias) & 7) == 0, "ovla_gemm_bf16: bias alignment");
   if (a->colscale) OVLA_REQUIRE((((uintptr_t)a->colscale) & 7) == 0, "ovla_gemm_bf16: colscale alignment");
   if (a->film_gamma) OVLA_REQUIRE(a->film_beta && a->film_rows > 0, "ovla_gemm_bf16: FiLM needs beta and film_rows");
+  if (a->rope_cos || a->rope_sin) {
+    OVLA_REQUIRE(a->rope_cos && a->rope_sin && a->rope_S > 0 && a->rope_cols > 0 && a->rope_cols <= a->N && (a->rope_cols % 128) == 0,
+                 "ovla_gemm_bf16: RoPE epilogue needs both tables, rope_S > 0 and rope_cols a multiple of the head dim 128 (<= N)");
+    OVLA_REQUIRE(!a->bias && !a->residual && !a->colscale && !a->film_gamma && !a->C_pre && !a->dact_src && a->act == OVLA_ACT_NONE &&
+                     (a->alpha == 0.f || a->alpha == 1.f),
+                 "ovla_gemm_bf16: the RoPE epilogue excludes the other epilogues");
+    OVLA_REQUIRE((((uintptr_t)a->rope_cos | (uintptr_t)a->rope_sin) & 7) == 0, "ovla_gemm_bf16: RoPE tables need 8-byte alignment");
+  }
   if (a->dact_src) {
     OVLA_REQUIRE(a->dact_mode == 1 || a->dact_mode == 2, "ovla_gemm_bf16: dact_mode %d (1 = activation derivative, 2 = SwiGLU)", a->dact_mode);
     OVLA_REQUIRE((a->ld_dact % 4) == 0 && (((uintptr_t)a->dact_src) & 7) == 0, "ovla_gemm_bf16: dact_src alignment");
@@ -874,6 +915,7 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   p.ws = (float*)a->workspace;
   p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
   p.dact_src = (const bf16_bits*)a->dact_src; p.ld_dact = a->ld_dact; p.dact_mode = a->dact_src ? a->dact_mode : 0; p.dact_act = a->dact_act;
+  p.rope_cos = nullptr; p.rope_sin = nullptr; p.rope_S = a->rope_S; p.rope_cols = a->rope_cols;   // enabled below for the config that fuses it
   p.T1 = cdiv(p.K, BK); p.T2 = p.K2 > 0 ? cdiv(p.K2, BK) : 0;
   if (p.split_k > p.T1 + p.T2) p.split_k = p.T1 + p.T2;
   p.full_tiles = 0; p.rem_tiles = 0; p.rem_splits = 1;
@@ -899,6 +941,22 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     else {   // 256x256 / 128x128 / 64x128 / 128x32 tiles, whichever the hybrid-schedule cost model predicts fastest
       hybrid = true;
       tile = pick_tile(p.M, p.N, T, p.k2_group_n, wsb / 4, nullptr);
+    }
+  }
+  if (a->rope_cos) {
+    // fused only where one wave slab is one head (256x256 tile, 4x2 waves) and the epilogue runs in-kernel or in the hybrid reduce;
+    // every other schedule computes the plain projection and rotates it with one ovla_rope launch (same arithmetic)
+    const bool fused = (tile == 17 || tile == 117) && p.split_k <= 1;
+    if (fused) {
+      p.rope_cos = (const bf16_bits*)a->rope_cos; p.rope_sin = (const bf16_bits*)a->rope_sin;
+    } else {
+      ovla_gemm_args plain = *a;
+      plain.rope_cos = plain.rope_sin = nullptr;
+      if (int rc = ovla_gemm_bf16(&plain, stream_)) return rc;
+      ovla_rope_args r = {};
+      r.qk = a->C; r.ld = a->ldc; r.rows = a->M; r.S = a->rope_S; r.n_heads = a->rope_cols / 128; r.head_dim = 128;
+      r.cos_table = a->rope_cos; r.sin_table = a->rope_sin; r.inverse = 0;
+      return ovla_rope(&r, stream_);
     }
   }
   switch (tile) {

@@ -32,6 +32,10 @@ F32 = torch.float32
 # (B = 8: none 177.1-177.6 ms/step, act 177.5-178.0, swiglu 178.0, all 178.1-178.4): a 256x256 tile owns its CU, so the extra epilogue
 # traffic is exposed, while the separate elementwise kernels already run at the HBM roofline.  Default: separate kernels.
 _FUSE = os.environ.get("OVLA_FUSE_DACT", "none")
+# Same story for the forward RoPE in the q|k|v projection's epilogue (bit-identical, 176.7-177.0 ms/step without vs 177.8-178.0 with:
+# two table loads + a partner LDS read per quad inside an exposed epilogue cost more than the 33 us HBM-roofline pass they replace).
+# The INVERSE RoPE of the backward, which needs no loads beyond the tables and no LDS (attention-backward epilogue), is on: -0.6 ms.
+_FUSE_ROPE_FWD = os.environ.get("OVLA_FUSE_ROPE_FWD", "0") == "1"
 _FUSE_ACT, _FUSE_SWIGLU = _FUSE in ("act", "all"), _FUSE in ("swiglu", "all")
 
 
@@ -189,15 +193,15 @@ class LoraLinear:
             ops.transpose(self.W, self.WT)
         self.merged = True
 
-    def fwd(self, x, *, act=0, residual=None, colscale=None, c_pre=None, film=None, out=None):
-        """x [M, in] -> (y [M, out], saved)."""
+    def fwd(self, x, *, act=0, residual=None, colscale=None, c_pre=None, film=None, out=None, rope=None):
+        """x [M, in] -> (y [M, out], saved).  `rope` = (cos, sin, S, cols): RoPE on the first `cols` output columns in the GEMM epilogue."""
         t_s = None
         if self.has_lora and not getattr(self, "merged", False):
             t_s = ops.gemm(x, self.A.data, alpha=self.scale)
             y = ops.gemm(x, self.W, out=out, bias=self.bias, act=act, residual=residual, colscale=colscale, c_pre=c_pre, film=film,
-                         a2=t_s, b2=self.B.data, k2_group_n=self.group_n if self.groups > 1 else 0)
+                         a2=t_s, b2=self.B.data, k2_group_n=self.group_n if self.groups > 1 else 0, rope=rope)
         else:
-            y = ops.gemm(x, self.W, out=out, bias=self.bias, act=act, residual=residual, colscale=colscale, c_pre=c_pre, film=film)
+            y = ops.gemm(x, self.W, out=out, bias=self.bias, act=act, residual=residual, colscale=colscale, c_pre=c_pre, film=film, rope=rope)
         return y, (x, t_s)
 
     def bwd(self, dy, saved, need_dx=True, dact=None):
@@ -441,8 +445,11 @@ class LlamaStack:
         saved = []
         for l in self.layers:
             h1, _, r1 = ops.norm_fwd(x, l["n1"], eps=cfg.rms_eps, rms=True, save_stats=train)
-            qkv, s_qkv = l["qkv"].fwd(h1)
-            ops.rope_(qkv, S, 2 * H, hd, cos, sin)
+            if _FUSE_ROPE_FWD and hd == 128:    # RoPE on the q | k heads in the projection's epilogue (ovla_gemm_args.rope_*)
+                qkv, s_qkv = l["qkv"].fwd(h1, rope=(cos, sin, S, 2 * D))
+            else:
+                qkv, s_qkv = l["qkv"].fwd(h1)
+                ops.rope_(qkv, S, 2 * H, hd, cos, sin)
             o, lse = ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, S, H, hd, kv_len=kv_len, causal=causal)
             x2, s_o = l["o"].fwd(o, residual=x)
             h2, _, r2 = ops.norm_fwd(x2, l["n2"], eps=cfg.rms_eps, rms=True, save_stats=train)

@@ -68,7 +68,7 @@ def check_device(index: int = 0) -> None:
 
 # ----------------------------------------------------------------------------------------------------------------------
 def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=None, c_pre=None, a2=None, b2=None,
-         k2_group_n=0, film=None, split_k=1, tile=0, alpha=1.0, a_group_n=0, dact=None):
+         k2_group_n=0, film=None, split_k=1, tile=0, alpha=1.0, a_group_n=0, dact=None, rope=None):
     """out[M,N] = epilogue(a[M,K] @ b[N,K]^T (+ a2[M,G*K2] @ b2[N,K2]^T)); all bf16 2-D, last dim contiguous."""
     _chk(a, name="a"); _chk(b, name="b")
     M, K = a.shape
@@ -110,6 +110,10 @@ def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=Non
         assert src.stride(1) == 1 and src.shape == (M, out_cols) and src.dtype == BF16
         g.dact_src, g.ld_dact = src.data_ptr(), src.stride(0)
         g.dact_mode, g.dact_act = (2, ACT_SILU) if dact[0] == "swiglu" else (1, dact[2])
+    if rope is not None:   # (cos, sin, S, cols): RoPE on output columns [0, cols) (q | k heads of a fused q|k|v projection), head_dim 128
+        cos, sin, rS, rcols = rope
+        assert cos.shape[1] == 64 and cos.shape[0] >= rS and cos.is_contiguous() and sin.is_contiguous()
+        g.rope_cos, g.rope_sin, g.rope_S, g.rope_cols = cos.data_ptr(), sin.data_ptr(), rS, rcols
     g.M, g.N, g.K, g.act, g.split_k, g.tile, g.alpha, g.a_group_n = M, N, K, act, split_k, tile, alpha, a_group_n
     ws = _workspace(a.device, max(4 * split_k * M * N if split_k > 1 else 0, _WS_BYTES))
     g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4

@@ -576,3 +576,20 @@ def test_attn_bwd_fused_inverse_rope(ops, dev, hd, S, causal):
     ops.attn_bwd(q, k, v, o, do, lse, B, S, H, hd, kv_len=kv_len, causal=causal, dq=d_fused[:, :D], dk=d_fused[:, D:2 * D], dv=d_fused[:, 2 * D:],
                  rope=(cos, sin))
     assert torch.equal(d_fused, d_ref)
+
+
+@pytest.mark.parametrize("M,S,tile", [(4864, 608, 0), (4864, 608, 117), (608, 608, 0), (1216, 304, 17), (700, 100, 1), (520, 130, 2)])
+def test_gemm_rope_epilogue(ops, dev, M, S, tile):
+    """RoPE in the q|k|v projection's epilogue (fused in the 256x256 config incl. its hybrid-remainder reduce; other schedules append
+    one ovla_rope launch) == plain GEMM followed by the separate RoPE pass, bit for bit.  3 heads of 128: q | k rotated, v untouched."""
+    torch.manual_seed(M + tile)
+    hd, K = 128, 512
+    N = 3 * 2 * hd                      # 2 q heads | 2 k heads | 2 v heads
+    a, b = rnd(M, K, dev=dev, scale=0.5), rnd(N, K, dev=dev, scale=0.1)
+    t, lb = rnd(M, 96, dev=dev), rnd(N, 32, dev=dev, scale=0.2)
+    cos, sin = ops.rope_table(S + 3, hd, 10000.0, dev)
+    kw = dict(a2=t, b2=lb, k2_group_n=N // 3, tile=tile)
+    ref = ops.gemm(a, b, **kw)
+    ops.rope_(ref, S, 4, hd, cos, sin)
+    got = ops.gemm(a, b, rope=(cos, sin, S, 4 * hd), **kw)
+    assert torch.equal(got, ref), f"{(got != ref).sum().item()} of {ref.numel()} differ"
