@@ -41,7 +41,8 @@ struct GemmParams {
   int fast_addr;  // 1: every staged byte offset fits in 32 bits (host-checked)
   const bf16_bits* dact_src; int64_t ld_dact; int dact_mode, dact_act;   // backward epilogues (ovla.h)
   const bf16_bits *rope_cos, *rope_sin; int rope_S, rope_cols;           // forward RoPE on columns [0, rope_cols), head_dim 128
-  int dbg;  // timing ablations (tools/gemm_ablate.py): bit0 = stage only the first two K tiles, bit1 = read fragments once, bit2 = every workgroup stages tile (0,0): all L2 hits
+  int fast_epi;  // host: only alpha / bias / residual in the epilogue and 16-byte aligned operands (unrolled read-back path)
+  int dbg;  // timing ablations (tools/gemm_ablate.py): bit0 = stage only the first two K tiles, bit1 = read fragments once, bit2 = every workgroup stages tile (0,0): all L2 hits, bit3 = no epilogue, bit4 = epilogue without its stores, bit5 = nontemporal stores, bit6 = force the LDS-staged epilogue
   int full_tiles, rem_tiles, rem_splits;  // hybrid schedule: tiles >= full_tiles are split rem_splits ways along K
 };
 
@@ -172,6 +173,11 @@ OVLA_DEV void epilogue_store(const GemmParams& p, int m, int n, f32x4 v) {
   bf16x4_bits o;
 #pragma unroll
   for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(v[j]);
+  if ((p.dbg & 16) && v[0] != 123.456f) return;            // timing ablation: the whole epilogue except the store
+  if (p.dbg & 32) {                                          // timing ablation: write-through store that does not stay in this XCD's L2
+    __builtin_nontemporal_store(o, reinterpret_cast<bf16x4_bits*>(p.C + (int64_t)m * p.ldc + n));
+    return;
+  }
   *reinterpret_cast<bf16x4_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
 }
 
@@ -378,6 +384,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   for (int j = 0; j < NT; ++j)
     acc[MT - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a_def, acc[MT - 1][j], 0, 0, 0);
 
+  if (p.dbg & 8) {   // timing ablation: no epilogue at all (one store per lane keeps the accumulators alive)
+    if (acc[0][0][0] == 123.456f) p.C[0] = 1;
+    return;
+  }
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // MFMA layout (operands swapped): lane owns C[m][n..n+3] with m = tile row (lane&15), n = 4*(lane>>4).
   if (rem_unit >= 0) {  // hybrid remainder unit: tile-local fp32 slab [rem_unit][BM][BN]
@@ -402,11 +412,66 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     return;
   }
   // Accumulators go through a wave-private fp32 LDS slab (32 rows at a time, row stride WTN+4 floats: conflict-free
-  // ds_write_b128) so that ONE rolled loop applies the epilogue and writes whole 128-byte row segments.
+  // ds_write_b128) and are read back row-major, so that every store instruction writes whole contiguous row segments (a
+  // direct 8-byte-per-lane store from the MFMA layout writes four 32-byte pieces per 128-byte line: measured 8-10 % of a
+  // 256x256 tile's time).  The slab is private to the wave: ONE workgroup barrier (the slabs alias the K-tile buffers other
+  // waves may still be reading), then only LDS waits.
   constexpr int LDSW = WTN + 4;
   constexpr int RM = MT < 2 ? MT : 2;  // m-tiles per round
   constexpr int QUADS = WTN / 4;       // 4-column groups per sub-tile row
   float* wstage = reinterpret_cast<float*>(smem_raw) + wave * (RM * 16 * LDSW);
+  // Fast path: interior tile with only the cheap epilogue terms (alpha, bias, residual: every Llama projection, forward and
+  // data-gradient).  Fully unrolled read-back, 8 columns = one 16-byte store per lane and step, no bounds checks, no per-element
+  // branches.  (tools/gemm_ablate.py, tile + 8000: the rolled general loop below cost 11-17 % of a 256x256 tile's time.)
+  if (p.fast_epi && !(p.dbg & 64) && m0 + BM <= p.M && n0 + BN <= p.N && (WTN % 8) == 0) {
+    constexpr int OCT = WTN / 8;                 // 8-column groups per slab row
+    constexpr int STEPS = RM * 16 * OCT / 64;    // read-back steps per round
+    const int mbase = m0 + wm * WTM, nbase = n0 + wn * WTN;
+    __syncthreads();
+#pragma unroll
+    for (int round = 0; round < MT / RM; ++round) {
+#pragma unroll
+      for (int ii = 0; ii < RM; ++ii)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          *reinterpret_cast<f32x4*>(wstage + (ii * 16 + (lane & 15)) * LDSW + j * 16 + 4 * (lane >> 4)) = acc[round * RM + ii][j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's own slab writes have landed
+      f32x4 lo[STEPS], hi[STEPS];
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        const int idx = st * 64 + lane, row = idx / OCT, c8 = idx % OCT;
+        lo[st] = *reinterpret_cast<const f32x4*>(wstage + row * LDSW + c8 * 8);
+        hi[st] = *reinterpret_cast<const f32x4*>(wstage + row * LDSW + c8 * 8 + 4);
+      }
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        const int idx = st * 64 + lane, row = idx / OCT, c8 = idx % OCT;
+        const int m = mbase + round * RM * 16 + row, n = nbase + c8 * 8;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] = lo[st][e] * p.alpha; x[4 + e] = hi[st][e] * p.alpha; }
+        if (p.bias) {
+          const bf16x8_bits b8 = *reinterpret_cast<const bf16x8_bits*>(p.bias + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = x[e] + bf2f((bf16_bits)b8[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = bfround(x[e]);
+        if (p.residual) {
+          const bf16x8_bits r8 = *reinterpret_cast<const bf16x8_bits*>(p.residual + (int64_t)m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = bfround(x[e] + bf2f((bf16_bits)r8[e]));
+        }
+        bf16x8_bits o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(x[e]);
+        *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (reads consumed above; keeps the next round's writes behind them)
+    }
+    return;
+  }
+  // General path (activations, pre-activation save, LayerScale, FiLM, backward epilogues, RoPE, edge tiles): one rolled loop.
 #pragma unroll
   for (int round = 0; round < MT / RM; ++round) {
     __syncthreads();  // main-loop LDS reads (round 0) / previous round's read-back are done
@@ -920,6 +985,8 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   if (p.split_k > p.T1 + p.T2) p.split_k = p.T1 + p.T2;
   p.full_tiles = 0; p.rem_tiles = 0; p.rem_splits = 1;
   p.dbg = (a->tile >= 1000) ? (a->tile / 1000) : 0;
+  p.fast_epi = !a->C_pre && a->act == OVLA_ACT_NONE && !a->colscale && !a->film_gamma && !a->dact_src && !a->rope_cos &&
+               (!a->residual || ((((uintptr_t)a->residual) & 15) == 0 && (a->ldr % 8) == 0)) && (!a->bias || (((uintptr_t)a->bias) & 15) == 0);
   p.fast_addr = ((int64_t)p.M * p.lda * 2 < (int64_t)4e9 && (int64_t)p.N * p.ldb * 2 < (int64_t)4e9) ? 1 : 0;
 
   int tile = a->tile % 1000;
