@@ -465,22 +465,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
         bf16x8_bits o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(x[e]);
-        *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
+        if (p.dbg & 32) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n));
+        else *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (reads consumed above; keeps the next round's writes behind them)
     }
     return;
   }
   // General path (activations, pre-activation save, LayerScale, FiLM, backward epilogues, RoPE, edge tiles): one rolled loop.
+  __syncthreads();  // every wave is done reading the K-tile buffers the slabs alias; from here on a wave touches only its own slab
 #pragma unroll
   for (int round = 0; round < MT / RM; ++round) {
-    __syncthreads();  // main-loop LDS reads (round 0) / previous round's read-back are done
 #pragma unroll
     for (int ii = 0; ii < RM; ++ii)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         *reinterpret_cast<f32x4*>(wstage + (ii * 16 + (lane & 15)) * LDSW + j * 16 + 4 * (lane >> 4)) = acc[round * RM + ii][j];
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
     for (int it = 0; it < RM * 16 * QUADS / 64; ++it) {
       const int idx = it * 64 + lane;

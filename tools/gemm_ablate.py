@@ -20,7 +20,7 @@ for (m, n, k) in [(4864, 22016, 4096), (4864, 12288, 4096), (4096, 4096, 4096), 
     out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
     fl = 2.0 * m * n * k
     row = []
-    for t in (117, 64117, 8117, 101, 64101):
+    for t in (117, 32117, 8117):
         ms = bench(lambda: ops.gemm(a, b, out=out, tile=t))
         row.append(f"tile{t}: {fl / ms / 1e9:6.0f}")
     print(m, n, k, " | ".join(row), flush=True)
