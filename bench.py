@@ -330,9 +330,9 @@ def main():
             d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fl
         ops.PROFILE = None
         # the dominant kernel = the gemm_nt instance with the most time in the step (ops._gemm_family names the instance each
-        # launch runs: t17 = gemm_nt_kernel<256,256,4,2>, t1 = <128,128,2,2>, t2 = <64,128,1,4>, t5 = <128,32,4,1>; a launch's
+        # launch runs: t17 = gemm_nt_kernel<256,256,2,4>, t1 = <128,128,2,2>, t2 = <64,128,1,4>, t5 = <128,32,4,1>; a launch's
         # events also cover its split-K / hybrid reduce kernel)
-        inst = {"gemm_nt_t17": "gemm_nt_kernel<256,256,4,2>", "gemm_nt_t1": "gemm_nt_kernel<128,128,2,2>", "gemm_nt_t2": "gemm_nt_kernel<64,128,1,4>",
+        inst = {"gemm_nt_t17": "gemm_nt_kernel<256,256,2,4>", "gemm_nt_t1": "gemm_nt_kernel<128,128,2,2>", "gemm_nt_t2": "gemm_nt_kernel<64,128,1,4>",
                 "gemm_nt_t5": "gemm_nt_kernel<128,32,4,1>"}
         gemms = {k: v for k, v in fam.items() if k.startswith("gemm_nt")}
         dom = max(gemms, key=lambda k: gemms[k][1])

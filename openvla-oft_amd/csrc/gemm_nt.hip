@@ -1014,7 +1014,7 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   if (a->rope_cos) {
     // fused only where one wave slab is one head (256x256 tile, 4x2 waves) and the epilogue runs in-kernel or in the hybrid reduce;
     // every other schedule computes the plain projection and rotates it with one ovla_rope launch (same arithmetic)
-    const bool fused = (tile == 17 || tile == 117) && p.split_k <= 1;
+    const bool fused = (tile == 16 || tile == 116) && p.split_k <= 1;
     if (fused) {
       p.rope_cos = (const bf16_bits*)a->rope_cos; p.rope_sin = (const bf16_bits*)a->rope_sin;
     } else {
@@ -1038,9 +1038,10 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     case 13: return launch_pipe<128, 256, 2, 4, 5>(p, stream);
     case 14: return launch_pipe<128, 128, 2, 2, 4>(p, stream);
     case 15: return launch_pipe<256, 256, 2, 4, 3>(p, stream);
-    case 16: return launch_cfg<256, 256, 2, 4>(p, stream);
-    case 17: return launch_cfg<256, 256, 4, 2>(p, stream, wsb, hybrid);
-    case 117: return launch_cfg<256, 256, 4, 2>(p, stream, wsb, true);
+    case 16: return launch_cfg<256, 256, 4, 2>(p, stream, wsb, hybrid);   // 4x2 waves (64x128 wave tiles): 1-3 % behind 2x4; one head per wave slab (fused RoPE)
+    case 116: return launch_cfg<256, 256, 4, 2>(p, stream, wsb, true);
+    case 17: return launch_cfg<256, 256, 2, 4>(p, stream, wsb, hybrid);   // 2x4 waves (128x64 wave tiles)
+    case 117: return launch_cfg<256, 256, 2, 4>(p, stream, wsb, true);
     case 101: return launch_cfg<128, 128, 2, 2>(p, stream, wsb, true);
     case 102: return launch_cfg<64, 128, 1, 4>(p, stream, wsb, true);
     case 105: return launch_cfg<128, 32, 4, 1>(p, stream, wsb, true);

@@ -125,7 +125,7 @@ def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=Non
 
 
 def _gemm_family(M, N, K, K2, k2_group_n, a_group_n, split_k, tile):
-    """Profiling only: which kernel instance `ovla_gemm_bf16` runs for this call ("gemm_nt_t17" = gemm_nt_kernel<256,256,4,2>, ...),
+    """Profiling only: which kernel instance `ovla_gemm_bf16` runs for this call ("gemm_nt_t17" = gemm_nt_kernel<256,256,2,4>, ...),
     from the same host-side decision the library makes (ovla_gemm_plan) -- so bench.py can report the dominant instance by itself."""
     import ctypes
 
