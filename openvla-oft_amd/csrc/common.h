@@ -23,9 +23,19 @@ OVLA_DEV bf16_bits f2bf(float f) {
 }
 OVLA_DEV float bfround(float f) { return bf2f(f2bf(f)); }
 
-OVLA_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): ~12 instructions (v_rcp, v_exp, 5 FMAs) instead of libm's branchy
+// erff (~100 executed instructions per wave with divergent lanes: it made the GELU epilogue of a ViT fc1 GEMM cost 40 % of the
+// launch).  The GELU outputs are rounded to bf16 (2^-9 relative) right after, three orders of magnitude coarser.
+OVLA_DEV float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float y = 1.0f - poly * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+OVLA_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 OVLA_DEV float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }

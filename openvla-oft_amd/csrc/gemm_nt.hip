@@ -41,7 +41,7 @@ struct GemmParams {
   int fast_addr;  // 1: every staged byte offset fits in 32 bits (host-checked)
   const bf16_bits* dact_src; int64_t ld_dact; int dact_mode, dact_act;   // backward epilogues (ovla.h)
   const bf16_bits *rope_cos, *rope_sin; int rope_S, rope_cols;           // forward RoPE on columns [0, rope_cols), head_dim 128
-  int fast_epi;  // host: only alpha / bias / residual in the epilogue and 16-byte aligned operands (unrolled read-back path)
+  int fast_epi;  // host: no FiLM / backward epilogue / RoPE and 16-byte aligned operands -> the unrolled read-back path applies
   int dbg;  // timing ablations (tools/gemm_ablate.py): bit0 = stage only the first two K tiles, bit1 = read fragments once, bit2 = every workgroup stages tile (0,0): all L2 hits, bit3 = no epilogue, bit4 = epilogue without its stores, bit5 = nontemporal stores, bit6 = force the LDS-staged epilogue
   int full_tiles, rem_tiles, rem_splits;  // hybrid schedule: tiles >= full_tiles are split rem_splits ways along K
 };
@@ -420,10 +420,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   constexpr int RM = MT < 2 ? MT : 2;  // m-tiles per round
   constexpr int QUADS = WTN / 4;       // 4-column groups per sub-tile row
   float* wstage = reinterpret_cast<float*>(smem_raw) + wave * (RM * 16 * LDSW);
-  // Fast path: interior tile with only the cheap epilogue terms (alpha, bias, residual: every Llama projection, forward and
-  // data-gradient).  Fully unrolled read-back, 8 columns = one 16-byte store per lane and step, no bounds checks, no per-element
-  // branches.  (tools/gemm_ablate.py, tile + 8000: the rolled general loop below cost 11-17 % of a 256x256 tile's time.)
-  if (p.fast_epi && !(p.dbg & 64) && m0 + BM <= p.M && n0 + BN <= p.N && (WTN % 8) == 0) {
+  // Fast path: interior tile, every epilogue term except FiLM / the backward epilogues / RoPE (alpha, bias, pre-activation save,
+  // activation, LayerScale, residual: every Llama and ViT projection, forward and data-gradient).  Fully unrolled read-back, 8 columns
+  // = one 16-byte store per lane and step, no bounds checks.  (tools/gemm_ablate.py, tile + 8000: the rolled general loop below cost
+  // 11-17 % of a 256x256 tile's time and 44 % of a ViT fc1 launch: bias + GELU + pre-activation save.)
+  // (the 256x256 configs hold 128 accumulator registers: unrolling the activation code there spills, and no 256x256-tiled GEMM of
+  // this model has an activation -- those keep the alpha / bias / residual subset)
+  constexpr bool FAST_ACT = MT * NT <= 16;
+  if (p.fast_epi && (FAST_ACT || (p.act == OVLA_ACT_NONE && !p.Cpre && !p.colscale)) && !(p.dbg & 64) && m0 + BM <= p.M && n0 + BN <= p.N &&
+      (WTN % 8) == 0) {
     constexpr int OCT = WTN / 8;                 // 8-column groups per slab row
     constexpr int STEPS = RM * 16 * OCT / 64;    // read-back steps per round
     const int mbase = m0 + wm * WTM, nbase = n0 + wn * WTN;
@@ -436,20 +441,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
         for (int j = 0; j < NT; ++j)
           *reinterpret_cast<f32x4*>(wstage + (ii * 16 + (lane & 15)) * LDSW + j * 16 + 4 * (lane >> 4)) = acc[round * RM + ii][j];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's own slab writes have landed
-      f32x4 lo[STEPS], hi[STEPS];
+      constexpr int GRP = STEPS < 2 ? STEPS : 2;   // read-back steps in flight (the accumulators of later rounds are still live)
 #pragma unroll
-      for (int st = 0; st < STEPS; ++st) {
-        const int idx = st * 64 + lane, row = idx / OCT, c8 = idx % OCT;
-        lo[st] = *reinterpret_cast<const f32x4*>(wstage + row * LDSW + c8 * 8);
-        hi[st] = *reinterpret_cast<const f32x4*>(wstage + row * LDSW + c8 * 8 + 4);
+      for (int st0 = 0; st0 < STEPS; st0 += GRP) {
+      f32x4 lo[GRP], hi[GRP];
+#pragma unroll
+      for (int s2 = 0; s2 < GRP; ++s2) {
+        const int idx = (st0 + s2) * 64 + lane, row = idx / OCT, c8 = idx % OCT;
+        lo[s2] = *reinterpret_cast<const f32x4*>(wstage + row * LDSW + c8 * 8);
+        hi[s2] = *reinterpret_cast<const f32x4*>(wstage + row * LDSW + c8 * 8 + 4);
       }
 #pragma unroll
-      for (int st = 0; st < STEPS; ++st) {
+      for (int s2 = 0; s2 < GRP; ++s2) {
+        const int st = st0 + s2;
         const int idx = st * 64 + lane, row = idx / OCT, c8 = idx % OCT;
         const int m = mbase + round * RM * 16 + row, n = nbase + c8 * 8;
         float x[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { x[e] = lo[st][e] * p.alpha; x[4 + e] = hi[st][e] * p.alpha; }
+        for (int e = 0; e < 4; ++e) { x[e] = lo[s2][e] * p.alpha; x[4 + e] = hi[s2][e] * p.alpha; }
         if (p.bias) {
           const bf16x8_bits b8 = *reinterpret_cast<const bf16x8_bits*>(p.bias + n);
 #pragma unroll
@@ -457,6 +466,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = bfround(x[e]);
+        if constexpr (FAST_ACT) {
+          if (p.Cpre) {        // value before the activation, saved for the backward
+            bf16x8_bits z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (short)f2bf(x[e]);
+            *reinterpret_cast<bf16x8_bits*>(p.Cpre + (int64_t)m * p.ldc + n) = z;
+          }
+          if (p.act != OVLA_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = bfround(apply_act(x[e], p.act));
+          }
+          if (p.colscale) {
+            const bf16x8_bits c8 = *reinterpret_cast<const bf16x8_bits*>(p.colscale + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = bfround(x[e] * bf2f((bf16_bits)c8[e]));
+          }
+        }
         if (p.residual) {
           const bf16x8_bits r8 = *reinterpret_cast<const bf16x8_bits*>(p.residual + (int64_t)m * p.ldr + n);
 #pragma unroll
@@ -467,6 +493,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
         for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(x[e]);
         if (p.dbg & 32) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n));
         else *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
+      }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (reads consumed above; keeps the next round's writes behind them)
     }
@@ -986,7 +1013,8 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   if (p.split_k > p.T1 + p.T2) p.split_k = p.T1 + p.T2;
   p.full_tiles = 0; p.rem_tiles = 0; p.rem_splits = 1;
   p.dbg = (a->tile >= 1000) ? (a->tile / 1000) : 0;
-  p.fast_epi = !a->C_pre && a->act == OVLA_ACT_NONE && !a->colscale && !a->film_gamma && !a->dact_src && !a->rope_cos &&
+  p.fast_epi = !a->film_gamma && !a->dact_src && !a->rope_cos && (!a->C_pre || (((uintptr_t)a->C_pre) & 15) == 0) &&
+               (!a->colscale || (((uintptr_t)a->colscale) & 15) == 0) &&
                (!a->residual || ((((uintptr_t)a->residual) & 15) == 0 && (a->ldr % 8) == 0)) && (!a->bias || (((uintptr_t)a->bias) & 15) == 0);
   p.fast_addr = ((int64_t)p.M * p.lda * 2 < (int64_t)4e9 && (int64_t)p.N * p.ldb * 2 < (int64_t)4e9) ? 1 : 0;
 
