@@ -403,14 +403,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // dK / dV: one workgroup per 64-key block (wave = 16 keys, key on the lane), loops over Q / dO tiles.
-template <int DP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnParams p) {
   constexpr int KS = DP / 32, DT = DP / 16, STRIDE = DP + 16;
-  __shared__ __attribute__((aligned(16))) bf16_bits Qs[BQ * STRIDE];
-  __shared__ __attribute__((aligned(16))) bf16_bits dOs[BQ * STRIDE];
-  __shared__ float Ls[BQ], Ds[BQ];
+  constexpr int NTH = 64 * NW;
+  constexpr int BKW = 16 * NW;   // keys per workgroup (NW = 8: 128 keys share every Q / dO tile)
+  // Q / dO tiles (+ their row statistics) are double buffered: tile t+1 is written while tile t is being read -> ONE barrier per tile
+  __shared__ __attribute__((aligned(16))) bf16_bits Qs[2][BQ * STRIDE];
+  __shared__ __attribute__((aligned(16))) bf16_bits dOs[2][BQ * STRIDE];
+  __shared__ float Ls[2][BQ], Ds[2][BQ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * BKV;
+  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * BKW;
   const int krow = k0 + wave * 16 + (lane & 15);
   const int krow_c = krow < p.S ? krow : p.S - 1;
   const int kvlen = p.kv_len ? p.kv_len[b] : p.S;
@@ -439,9 +442,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
   const int nq = (p.S + BQ - 1) / BQ;
   const int qt0 = p.causal ? (k0 / BQ) : 0;
 
-  TileStage<DP> qst, dst;
+  TileStage<DP, NTH> qst, dst;
   float lreg = 0.f, dreg = 0.f;
-  auto load_stats = [&](int qt) {
+  auto load_tile = [&](int qt) {
+    qst.load(Qb, p.q_stride, qt * BQ, p.S - 1, p.hd, tid);
+    dst.load(dOb, p.do_stride, qt * BQ, p.S - 1, p.hd, tid);
     if (tid < BQ) {
       int r = qt * BQ + tid;
       r = r < p.S ? r : p.S - 1;
@@ -449,67 +454,86 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
       dreg = del_b[r];
     }
   };
-  if (qt0 < nq) {
-    qst.load(Qb, p.q_stride, qt0 * BQ, p.S - 1, p.hd, tid);
-    dst.load(dOb, p.do_stride, qt0 * BQ, p.S - 1, p.hd, tid);
-    load_stats(qt0);
-  }
-  for (int qt = qt0; qt < nq; ++qt) {
-    __syncthreads();
-    qst.store(Qs, tid);
-    dst.store(dOs, tid);
+  auto store_tile = [&](int buf) {
+    qst.store(Qs[buf], tid);
+    dst.store(dOs[buf], tid);
     if (tid < BQ) {
-      Ls[tid] = lreg;
-      Ds[tid] = dreg;
+      Ls[buf][tid] = lreg;
+      Ds[buf][tid] = dreg;
     }
-    __syncthreads();
-    if (qt + 1 < nq) {
-      qst.load(Qb, p.q_stride, (qt + 1) * BQ, p.S - 1, p.hd, tid);
-      dst.load(dOb, p.do_stride, (qt + 1) * BQ, p.S - 1, p.hd, tid);
-      load_stats(qt + 1);
-    }
-    // S[q][key], dP[q][key] with key = lane&15, q = 16 mt + 4 g + j
-    f32x4 accS[4], accP[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      accS[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      accP[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        accS[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Qs, mt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), kf[s],
-                                                           accS[mt], 0, 0, 0);
-        accP[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(dOs, mt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), vf[s],
-                                                           accP[mt], 0, 0, 0);
-      }
-    }
+  };
+  if (qt0 < nq) {
+    load_tile(qt0);
+    store_tile(0);
+    if (qt0 + 1 < nq) load_tile(qt0 + 1);
+  }
+  __syncthreads();
+
+  auto tile = [&](int qt, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    const int buf = (qt - qt0) & 1;
+    const bf16_bits* Qt = Qs[buf];
+    const bf16_bits* dOt = dOs[buf];
+    const float* Lt = Ls[buf];
+    const float* Dt = Ds[buf];
     const int qbase = qt * BQ;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ql = mt * 16 + 4 * g + j;
-        const int q = qbase + ql;
-        const bool ok = key_ok && q < p.S && (!p.causal || krow <= q);
-        const float pv = ok ? __builtin_amdgcn_exp2f(accS[mt][j] * sl2 - Ls[ql]) : 0.f;
-        accS[mt][j] = pv;                              // P
-        accP[mt][j] = pv * (accP[mt][j] - Ds[ql]);     // dS (unscaled)
-      }
+    // the two halves of the 64-row tile go through S / dP -> P / dS -> dV / dK one after the other (halves the live S / dP tiles)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
+      // S[q][key], dP[q][key] with key = lane&15, q = 16 mt + 4 g + j
+      f32x4 accS[2], accP[2];
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm) {
+        const int mt = 2 * s2 + mm;
+        accS[mm] = f32x4{0.f, 0.f, 0.f, 0.f};
+        accP[mm] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          accS[mm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Qt, mt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), kf[s], accS[mm], 0, 0, 0);
+          accP[mm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(dOt, mt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), vf[s], accP[mm], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ql = (2 * s2 + mm) * 16 + 4 * g + j;
+          float pv = __builtin_amdgcn_exp2f(accS[mm][j] * sl2 - Lt[ql]);
+          if constexpr (MASK) {
+            const int q = qbase + ql;
+            const bool ok = key_ok && q < p.S && (!p.causal || krow <= q);
+            pv = ok ? pv : 0.f;
+          }
+          accS[mm][j] = pv;                              // P
+          accP[mm][j] = pv * (accP[mm][j] - Dt[ql]);     // dS (unscaled)
+        }
       bf16x8_bits pf, dsf;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        pf[j] = f2bf_s(accS[2 * s2][j]);
-        pf[4 + j] = f2bf_s(accS[2 * s2 + 1][j]);
-        dsf[j] = f2bf_s(accP[2 * s2][j]);
-        dsf[4 + j] = f2bf_s(accP[2 * s2 + 1][j]);
+        pf[j] = f2bf_s(accS[0][j]);
+        pf[4 + j] = f2bf_s(accS[1][j]);
+        dsf[j] = f2bf_s(accP[0][j]);
+        dsf[4 + j] = f2bf_s(accP[1][j]);
       }
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
-        accV[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(dOs, 32 * s2, d * 16, STRIDE, lane), pf, accV[d], 0, 0, 0);
-        accK[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Qs, 32 * s2, d * 16, STRIDE, lane), dsf, accK[d], 0, 0, 0);
+        accV[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(dOt, 32 * s2, d * 16, STRIDE, lane), pf, accV[d], 0, 0, 0);
+        accK[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Qt, 32 * s2, d * 16, STRIDE, lane), dsf, accK[d], 0, 0, 0);
       }
     }
+    if (qt + 1 < nq) {   // tile qt+1 (in registers since the previous iteration) -> the other buffer; fetch tile qt+2
+      store_tile(buf ^ 1);
+      if (qt + 2 < nq) load_tile(qt + 2);
+    }
+    __syncthreads();
+  };
+  // Interior query tiles need no mask code when every key of this workgroup is valid (no key padding inside the block, no causal
+  // diagonal in the tile) and the tile has 64 real rows; everything else takes the masked body.
+  const bool keys_full = k0 + BKW <= kvlen && k0 + BKW <= p.S;
+  for (int qt = qt0; qt < nq; ++qt) {
+    const bool free_tile = keys_full && (qt + 1) * BQ <= p.S && (!p.causal || qt * BQ >= k0 + BKW - 1);
+    if (free_tile) tile(qt, std::false_type{});
+    else tile(qt, std::true_type{});
   }
   if (krow < p.S) {
     bf16_bits* dKb = p.dK + ((int64_t)b * p.S + krow) * p.dk_stride + (int64_t)h * p.hd;
@@ -601,18 +625,19 @@ extern "C" int ovla_attn_bwd(const ovla_attn_bwd_args* a, void* stream_) {
   hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(items, 16)), dim3(256), 0, stream, p);
   OVLA_CHECK_LAUNCH("ovla_attn_bwd(delta)");
   const dim3 grid(cdiv(a->S, BQ), a->H, a->B);
+  const dim3 grid_kv4(cdiv(a->S, 64), a->H, a->B), grid_kv8(cdiv(a->S, 128), a->H, a->B);
   switch (a->head_dim) {
     case 64:
       hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, dim3(256), 0, stream, p);
-      hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 4>), grid_kv4, dim3(256), 0, stream, p);
       break;
     case 72:
       hipLaunchKernelGGL(attn_bwd_dq_kernel<96>, grid, dim3(256), 0, stream, p);
-      hipLaunchKernelGGL(attn_bwd_dkv_kernel<96>, grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<96, 4>), grid_kv4, dim3(256), 0, stream, p);
       break;
-    default:
+    default:   // the Llama shape: 8 waves = 128 keys share every Q / dO tile
       hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, stream, p);
-      hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 8>), grid_kv8, dim3(512), 0, stream, p);
       break;
   }
   OVLA_CHECK_LAUNCH("ovla_attn_bwd");
