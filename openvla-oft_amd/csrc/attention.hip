@@ -297,18 +297,21 @@ OVLA_DEV void inverse_rope_store(const f32x4 (&acc)[DT], float scale, bf16_bits*
   }
 }
 
-template <int DP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParams p) {
   constexpr int KS = DP / 32, DT = DP / 16, STRIDE = DP + 16;
-  __shared__ __attribute__((aligned(16))) bf16_bits Ks[BKV * STRIDE];
-  __shared__ __attribute__((aligned(16))) bf16_bits Vs[BKV * STRIDE];
+  constexpr int NTH = 64 * NW;
+  constexpr int BQW = 16 * NW;   // query rows per workgroup (NW = 8: 128 rows share every K / V tile)
+  // K / V tiles double buffered in LDS (as in the forward): ONE barrier per key tile
+  __shared__ __attribute__((aligned(16))) bf16_bits Ks[2][BKV * STRIDE];
+  __shared__ __attribute__((aligned(16))) bf16_bits Vs[2][BKV * STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQ;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQW;
   const int qrow = q0 + wave * 16 + (lane & 15);
   const int qrow_c = qrow < p.S ? qrow : p.S - 1;
   const int kvlen = p.kv_len ? p.kv_len[b] : p.S;
   int kv_end = kvlen < p.S ? kvlen : p.S;
-  if (p.causal) kv_end = kv_end < (q0 + BQ) ? kv_end : (q0 + BQ);
+  if (p.causal) kv_end = kv_end < (q0 + BQW) ? kv_end : (q0 + BQW);
   const int ntiles = (kv_end + BKV - 1) / BKV;
 
   const bf16_bits* Qb = p.Q + (int64_t)b * p.S * p.q_stride + (int64_t)h * p.hd;
@@ -331,56 +334,70 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
 #pragma unroll
   for (int d = 0; d < DT; ++d) accQ[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  TileStage<DP> kst, vst;
+  TileStage<DP, NTH> kst, vst;
   if (ntiles > 0) {
     kst.load(Kb, p.k_stride, 0, p.S - 1, p.hd, tid);
     vst.load(Vb, p.v_stride, 0, p.S - 1, p.hd, tid);
+    kst.store(Ks[0], tid);
+    vst.store(Vs[0], tid);
+    if (ntiles > 1) {
+      kst.load(Kb, p.k_stride, BKV, p.S - 1, p.hd, tid);
+      vst.load(Vb, p.v_stride, BKV, p.S - 1, p.hd, tid);
+    }
   }
-  for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();
-    kst.store(Ks, tid);
-    vst.store(Vs, tid);
-    __syncthreads();
-    if (t + 1 < ntiles) {
-      kst.load(Kb, p.k_stride, (t + 1) * BKV, p.S - 1, p.hd, tid);
-      vst.load(Vb, p.v_stride, (t + 1) * BKV, p.S - 1, p.hd, tid);
-    }
-    f32x4 accS[4], accP[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      accS[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      accP[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        accS[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, nt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), qf[s],
-                                                           accS[nt], 0, 0, 0);
-        accP[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vs, nt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), dof[s],
-                                                           accP[nt], 0, 0, 0);
-      }
-    }
+  __syncthreads();
+  auto tile = [&](int t, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    const bf16_bits* Kt = Ks[t & 1];
+    const bf16_bits* Vt = Vs[t & 1];
     const int kbase = t * BKV;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int key = kbase + nt * 16 + 4 * g + j;
-        const bool ok = key < kvlen && (!p.causal || key <= qrow);
-        const float pv = ok ? __builtin_amdgcn_exp2f(accS[nt][j] * sl2 - Lq) : 0.f;
-        accS[nt][j] = pv * (accP[nt][j] - Dq);  // dS (unscaled)
-      }
+    // the two 32-key halves go through S / dP -> dS -> dQ one after the other (halves the live S / dP tiles)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
+      f32x4 accS[2], accP[2];
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn) {
+        const int nt = 2 * s2 + nn;
+        accS[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        accP[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          accS[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Kt, nt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), qf[s], accS[nn], 0, 0, 0);
+          accP[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vt, nt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), dof[s], accP[nn], 0, 0, 0);
+        }
+      }
       bf16x8_bits dsf;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        dsf[j] = f2bf_s(accS[2 * s2][j]);
-        dsf[4 + j] = f2bf_s(accS[2 * s2 + 1][j]);
-      }
+      for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float pv = __builtin_amdgcn_exp2f(accS[nn][j] * sl2 - Lq);
+          if constexpr (MASK) {
+            const int key = kbase + (2 * s2 + nn) * 16 + 4 * g + j;
+            const bool ok = key < kvlen && (!p.causal || key <= qrow);
+            pv = ok ? pv : 0.f;
+          }
+          dsf[4 * nn + j] = f2bf_s(pv * (accP[nn][j] - Dq));   // dS (unscaled)
+        }
 #pragma unroll
       for (int d = 0; d < DT; ++d)
-        accQ[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Ks, 32 * s2, d * 16, STRIDE, lane), dsf, accQ[d], 0, 0, 0);
+        accQ[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Kt, 32 * s2, d * 16, STRIDE, lane), dsf, accQ[d], 0, 0, 0);
     }
-  }
+    if (t + 1 < ntiles) {   // tile t+1 (in registers since the previous iteration) -> the other LDS buffer; fetch tile t+2
+      kst.store(Ks[(t + 1) & 1], tid);
+      vst.store(Vs[(t + 1) & 1], tid);
+      if (t + 2 < ntiles) {
+        kst.load(Kb, p.k_stride, (t + 2) * BKV, p.S - 1, p.hd, tid);
+        vst.load(Vb, p.v_stride, (t + 2) * BKV, p.S - 1, p.hd, tid);
+      }
+    }
+    __syncthreads();
+  };
+  int n_free = kvlen / BKV;     // tiles whose every key is valid for every row of this workgroup run the body without mask code
+  if (p.causal) n_free = n_free < (q0 / BKV) ? n_free : (q0 / BKV);
+  if (n_free > ntiles) n_free = ntiles;
+  for (int t = 0; t < n_free; ++t) tile(t, std::false_type{});
+  for (int t = n_free; t < ntiles; ++t) tile(t, std::true_type{});
   if (qrow < p.S) {
     bf16_bits* dQb = p.dQ + ((int64_t)b * p.S + qrow) * p.dq_stride + (int64_t)h * p.hd;
     if (p.rope_cos) {
@@ -628,15 +645,15 @@ extern "C" int ovla_attn_bwd(const ovla_attn_bwd_args* a, void* stream_) {
   const dim3 grid_kv4(cdiv(a->S, 64), a->H, a->B), grid_kv8(cdiv(a->S, 128), a->H, a->B);
   switch (a->head_dim) {
     case 64:
-      hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<64, 4>), grid, dim3(256), 0, stream, p);
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 4>), grid_kv4, dim3(256), 0, stream, p);
       break;
     case 72:
-      hipLaunchKernelGGL(attn_bwd_dq_kernel<96>, grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<96, 4>), grid, dim3(256), 0, stream, p);
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<96, 4>), grid_kv4, dim3(256), 0, stream, p);
       break;
     default:   // the Llama shape: 8 waves = 128 keys share every Q / dO tile
-      hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 8>), grid_kv8, dim3(512), 0, stream, p);
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 8>), grid_kv8, dim3(512), 0, stream, p);
       break;
   }
