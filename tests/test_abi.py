@@ -66,3 +66,18 @@ def test_missing_library_fails_loudly(libmod, monkeypatch, tmp_path):
     monkeypatch.setattr(libmod, "LIB_PATH", tmp_path / "nope.so")
     with pytest.raises(RuntimeError, match="no fallback"):
         libmod.lib()
+
+
+def test_integration_md_struct_matches_header():
+    """The ctypes struct INTEGRATION.md shows a maintainer must have the header's field order (a stale snippet would corrupt arguments)."""
+    import re
+    from pathlib import Path
+
+    lib_mod = importlib.import_module("openvla-oft_amd._lib")
+    text = (Path(__file__).resolve().parent.parent / "INTEGRATION.md").read_text()
+    block = text[text.index("class ovla_gemm_args(ctypes.Structure):"): text.index("def linear_bf16(")]
+    doc_fields = re.findall(r'\("(\w+)", ctypes\.(\w+)\)', block)
+    kinds = {"c_void_p": "c_void_p", "c_int64": "c_long", "c_int32": "c_int", "c_float": "c_float"}
+    hdr = [(n, t.__name__) for n, t in lib_mod.STRUCTS["ovla_gemm_args"]._fields_]
+    assert [n for n, _ in doc_fields] == [n for n, _ in hdr]
+    assert all(kinds[d] == h or (d == "c_int64" and h in ("c_long", "c_longlong")) for (_, d), (_, h) in zip(doc_fields, hdr))
