@@ -16,6 +16,7 @@
 //   * block ids are remapped so each XCD (private L2) owns a contiguous band of tiles, grouped 8 tile-rows deep.
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 #include <algorithm>
 #include <stdarg.h>
 
@@ -529,6 +530,73 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
 }
 
 // =====================================================================================================================
+// Skinny-N, short-K GEMM in ONE launch (the ViT LoRA projections t = s x A^T and dt = s dy B: N = 32, K 1k..4k, M ~ 4k): the tiled
+// split-K path needs two launches (GEMM + reduce), ~20 us of mostly launch / ramp latency for 9 MB of input.  Here one workgroup
+// owns 32 rows x all N columns, its 4 waves split K and reduce through LDS.  Both MFMA operands are K-contiguous in memory, so
+// every lane loads its 16-byte fragments straight from global (A streams from HBM once; B, N x K <= 280 KB, stays in L2).
+// Used only where it wins (N == 32, K <= 3072: 13.3 vs 16.4 us back to back; beyond that the split-K pair is faster, and at N = 96
+// the B re-reads from L2, once per 32 rows, made it slower at every K).
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const GemmParams p) {
+  constexpr int LDW = NT * 16 + 4;
+  __shared__ __attribute__((aligned(16))) float red[4][32][LDW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * 32;
+  const int ksteps = (p.K + 31) / 32;
+  const int per_wave = (ksteps + 3) / 4;
+  const int ks0 = wave * per_wave, ks1 = (ks0 + per_wave) < ksteps ? (ks0 + per_wave) : ksteps;
+  const int kq = 8 * (lane >> 4);
+  const bf16_bits* arow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0 + i * 16 + (lane & 15);
+    m = m < p.M ? m : p.M - 1;
+    arow[i] = p.A + (int64_t)m * p.lda;
+  }
+  const bf16_bits* brow = p.B + (int64_t)(lane & 15) * p.ldb;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x8_bits zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+  for (int ks = ks0; ks < ks1; ++ks) {
+    const int k = ks * 32 + kq;
+    const bool kin = k < p.K;
+    bf16x8_bits a[2], b[NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = kin ? *reinterpret_cast<const bf16x8_bits*>(arow[i] + k) : zero;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b[j] = kin ? *reinterpret_cast<const bf16x8_bits*>(brow + (int64_t)j * 16 * p.ldb + k) : zero;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+  }
+  // cross-wave K reduction through LDS; lane owns C[m = i*16 + (lane&15)][n = j*16 + 4*(lane>>4) .. +3]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(&red[wave][i * 16 + (lane & 15)][j * 16 + 4 * (lane >> 4)]) = acc[i][j];
+  __syncthreads();
+  constexpr int QUADS = NT * 4;
+  for (int idx = tid; idx < 32 * QUADS; idx += 256) {
+    const int row = idx / QUADS, c4 = (idx % QUADS) * 4;
+    const int m = m0 + row;
+    if (m >= p.M) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][row][c4]);
+    v += *reinterpret_cast<const f32x4*>(&red[1][row][c4]);
+    v += *reinterpret_cast<const f32x4*>(&red[2][row][c4]);
+    v += *reinterpret_cast<const f32x4*>(&red[3][row][c4]);
+    bf16x4_bits o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(v[j] * p.alpha);
+    *reinterpret_cast<bf16x4_bits*>(p.C + (int64_t)m * p.ldc + c4) = o;
+  }
+}
+
+// =====================================================================================================================
 // Deep-pipelined variant (large tiles, ~1 workgroup per CU).
 //   * BK = 32 stages in a STAGES-deep LDS ring: STAGES-1 stages of LDS-DMA stay in flight across the per-stage barrier
 //     (counted s_waitcnt vmcnt, raw s_barrier -- __syncthreads() would drain the DMA queue, cdna_hip_programming.md
@@ -1031,6 +1099,13 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
       while (sp < 8 && tiles * sp < 256 && (sp * 2) * 8 <= T && ovla_gemm_workspace_bytes(p.M, p.N, sp * 2) <= wsb) sp *= 2;
       return sp;
     };
+    static const bool skinny_on = []() { const char* e = getenv("OVLA_SKINNY"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (skinny_on && p.N == 32 && p.a_group_n == 0 && p.K <= 3072 && p.M >= 512 && p.K2 == 0 && p.split_k <= 1 && !a->bias && !a->C_pre && !a->colscale &&
+        !a->residual && !a->film_gamma && !a->dact_src && !a->rope_cos && a->act == OVLA_ACT_NONE) {
+      hipLaunchKernelGGL(gemm_skinny_kernel<2>, dim3((unsigned)cdiv(p.M, 32)), dim3(256), 0, stream, p);
+      OVLA_CHECK_LAUNCH("ovla_gemm_bf16(skinny)");
+      return OVLA_OK;
+    }
     if (p.N <= 32 || p.a_group_n == 32) { tile = 5; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 128) * cdiv(p.N, 32)); }
     else if (p.a_group_n > 0) { tile = 1; }
     else if (p.M <= 64 || p.N <= 128) { tile = 2; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 64) * cdiv(p.N, 128)); }
@@ -1060,6 +1135,10 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     case 2: return launch_cfg<64, 128, 1, 4>(p, stream, wsb, hybrid);
     case 3: return launch_cfg<256, 128, 4, 2>(p, stream);
     case 5: return launch_cfg<128, 32, 4, 1>(p, stream, wsb, hybrid);
+    case 6:
+      hipLaunchKernelGGL(gemm_skinny_kernel<2>, dim3((unsigned)cdiv(p.M, 32)), dim3(256), 0, stream, p);
+      OVLA_CHECK_LAUNCH("ovla_gemm_bf16(skinny)");
+      return OVLA_OK;
     case 10: return launch_pipe<256, 256, 2, 4, 4>(p, stream);
     case 11: return launch_pipe<256, 128, 2, 4, 5>(p, stream);
     case 12: return launch_pipe<256, 128, 4, 2, 5>(p, stream);

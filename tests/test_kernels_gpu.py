@@ -151,7 +151,8 @@ def test_gemm_hybrid_schedule(ops, dev, M, N, K, tile):
 def test_gemm_auto_skinny(ops, dev):
     """tile=0 picks split-K for skinny outputs (LoRA t / dt) and small M (action head)."""
     torch.manual_seed(12)
-    for M, N, K in [(4864, 96, 4096), (4864, 32, 11008), (64, 4096, 28672), (1000, 64, 1152)]:
+    for M, N, K in [(4864, 96, 4096), (4864, 32, 11008), (64, 4096, 28672), (1000, 64, 1152), (4176, 32, 1024), (4100, 32, 3072), (522, 32, 1160),
+                    (1030, 32, 72)]:   # the last four take the single-launch skinny kernel (N = 32, K <= 3072)
         a, b = rnd(M, K, dev=dev, scale=0.3), rnd(N, K, dev=dev, scale=0.1)
         close(ops.gemm(a, b, alpha=0.5), (0.5 * (a.float() @ b.float().T)).to(BF), what=f"auto skinny {M}x{N}x{K}")
 
