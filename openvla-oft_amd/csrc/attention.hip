@@ -649,8 +649,13 @@ extern "C" int ovla_attn_bwd(const ovla_attn_bwd_args* a, void* stream_) {
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<64, 4>), grid_kv4, dim3(256), 0, stream, p);
       break;
     case 72:
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<96, 4>), grid, dim3(256), 0, stream, p);
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<96, 4>), grid_kv4, dim3(256), 0, stream, p);
+      if (a->S % 128 == 0 || a->S > 512) {   // SigLIP: 256 tokens = two exact 128-row blocks
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<96, 8>), grid_kv8, dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<96, 8>), grid_kv8, dim3(512), 0, stream, p);
+      } else {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<96, 4>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<96, 4>), grid_kv4, dim3(256), 0, stream, p);
+      }
       break;
     default:   // the Llama shape: 8 waves = 128 keys share every Q / dO tile
       hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 8>), grid_kv8, dim3(512), 0, stream, p);
