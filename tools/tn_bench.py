@@ -13,8 +13,10 @@ def bench(fn, iters=40):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-M, r = 4864, 32
-for name, inn, out, G in [("qkv", 4096, 12288, 3), ("o", 4096, 4096, 1), ("gate_up", 4096, 22016, 2), ("down", 11008, 4096, 1)]:
+r = 32
+for name, M, inn, out, G in [("qkv", 4864, 4096, 12288, 3), ("o", 4864, 4096, 4096, 1), ("gate_up", 4864, 4096, 22016, 2), ("down", 4864, 11008, 4096, 1),
+                             ("vit qkv", 4176, 1024, 3072, 1), ("vit proj", 4176, 1024, 1024, 1), ("vit fc1", 4176, 1024, 4096, 1), ("vit fc2", 4176, 4096, 1024, 1),
+                             ("sig fc1", 4096, 1152, 4304, 1)]:
     gn = out // G
     x = torch.randn(M, inn, device=dev).to(BF); dy = torch.randn(M, out, device=dev).to(BF)
     t = torch.randn(M, G * r, device=dev).to(BF); dt = torch.randn(M, G * r, device=dev).to(BF)
