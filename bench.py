@@ -269,7 +269,8 @@ def main():
     batch["proprio"] = batch["proprio"].to(dev, torch.bfloat16)
     S = 1 + cfg.num_images * cfg.dino.n_patches + 1 + int(args.aloha) + (batch["input_ids"].shape[1] - 1)   # (+1: diffusion timestep token)
     reducer = dp_mod.GradReducer(eng.stores, world) if world > 1 else None
-    eng.attach_reducer(reducer)
+    # gradient all-reduce overlapped with the backward (buckets ship as they complete); OVLA_DP_OVERLAP=0 reduces everything after it
+    eng.attach_reducer(reducer, overlap=os.environ.get("OVLA_DP_OVERLAP", "1") != "0")
     if rank == 0:
         print(f"[bench] init {time.time() - t_init:.1f}s, trainable params {eng.num_trainable() / 1e6:.1f} M, S={S}, "
               f"HBM allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB", file=sys.stderr)

@@ -241,7 +241,7 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
         log(f"[finetune] resumed step {cfg.resume_step} from {cfg.vla_path}: {info['tensors']} tensors, optimizer state: {info['optimizer']}, "
             f"{len(info['missing'])} trainable tensors kept at their initial values")
     reducer = GradReducer(engine.stores, world) if world > 1 else None
-    engine.attach_reducer(reducer, overlap=cfg.grad_accumulation_steps == 1)   # overlap only when every backward ends a step
+    engine.attach_reducer(reducer, overlap=cfg.grad_accumulation_steps == 1 and os.environ.get("OVLA_DP_OVERLAP", "1") != "0")   # overlap only when every backward ends a step
     if dataset is None:
         def synthetic_stream():
             step = 0
