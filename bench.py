@@ -345,7 +345,7 @@ def main():
                     # HBM-side bytes per launch from PMC counters cannot be collected from inside this process; the value below is
                     # the measured, gfx950-corrected FETCH_SIZE*2 + WRITE_SIZE of the most expensive shape (gate|up forward,
                     # 4864x22016x4096; 4.34e8 algorithmic bytes), see profiles/r01_pmc_gemm_gate_up.md
-                    "traffic": 1.754e9 if not args.tiny else None,
+                    "traffic": 1.62e9 if not args.tiny else None,
                     "launches_per_step": n, "avg_launch_us": 1e3 * ms / n, "flops_per_step": fl, "ms_per_step": ms,
                     "all_gemm_nt": {"launches": all_n, "ms": all_ms, "flops_per_step": all_fl, "tflops": all_fl / (all_ms * 1e-3) / 1e12,
                                     "by_instance": {inst.get(k, k): {"launches": v[0], "ms": v[1], "tflops": v[2] / (v[1] * 1e-3) / 1e12}
