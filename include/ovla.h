@@ -235,6 +235,28 @@ int ovla_im2col(const ovla_im2col_args* a, void* stream);
 typedef struct { const void* src; void* dst; int32_t n_img, H, W, out, crop; float crop_scale; float mean[6]; float std[6]; } ovla_image_prep_args;
 int ovla_image_prep(const ovla_image_prep_args* a, void* stream);
 
+/* Training-time image path as two launches (replaces the TF/dlimp frame transform + PIL/torchvision processor of the reference's data
+ * loader: prismatic/vla/datasets/rlds/obs_transforms.py:18-45 `augment` -> dlimp `augment_image` with the kwargs of
+ * prismatic/vla/datasets/datasets.py:159-174, then prismatic/extern/hf/processing_prismatic.py:128-145 `apply_transform`).
+ * Per image, fp32, every operation individually rounded (no FMA contraction), `clip(0, 1)` after every enabled op:
+ *   x = u8 / 255
+ *   bit 0  crop_and_resize(box = params[0..3] = y1, x1, y2, x2, to out x out)   TF CropAndResize, bilinear, extrapolation 0
+ *   bit 1  x + params[4]                                                        tf.image.adjust_brightness
+ *   bit 2  (x - mean_c) * params[5] + mean_c, mean over the image per channel   AdjustContrastv2 (mean accumulated in fp64 here)
+ *   bit 3  rgb -> hsv, s = clamp(s * params[6], 0, 1), hsv -> rgb                adjust_saturation_op.cc (CPU kernel arithmetic)
+ *   bit 4  rgb -> (h, v_min, v_max), h += 6 * params[7] wrapped to [0, 6), back  adjust_hue_op.cc (CPU kernel arithmetic)
+ *   u8 = trunc(x * 255); then to_tensor (/255) and the two backbones' normalisations as in ovla_image_prep.
+ * ops_mask == 0 is the evaluation path (quantise + normalise only; H == W == out required unless bit 0 is set).
+ * src uint8 [n_img, H, W, 3] (device) ; params fp32 [n_img, 8] (device) ; dst bf16 [n_img, 6, out, out] ;
+ * workspace: ovla_image_augment_workspace_bytes(n_img, out) bytes (fp32 intermediate image + per-block fp64 channel sums).
+ * TensorFlow / dlimp are not available offline: PARITY UNPINNED against TF, bit-compared with oracle/data_oracle.py. */
+typedef struct {
+  const void* src; void* dst; const float* params; void* workspace; int64_t workspace_bytes;
+  int32_t n_img, H, W, out, ops_mask; float mean[6]; float std[6];
+} ovla_image_augment_args;
+int64_t ovla_image_augment_workspace_bytes(int32_t n_img, int32_t out);
+int ovla_image_augment(const ovla_image_augment_args* a, void* stream);
+
 /* tokens[b, pre + i, :] = patches[b, i, :] + pos[i, :] ;  tokens[b, j, :] = prefix[j, :]  (cls / register tokens)
  * (timm VisionTransformer._pos_embed with no_embed_class=True) */
 typedef struct { const void* patches; const void* pos; const void* prefix; void* tokens; int32_t B, n_patches, n_prefix, dim; } ovla_vit_embed_args;

@@ -674,7 +674,250 @@ __global__ __launch_bounds__(256) void image_prep_kernel(const ImagePrepParams p
     }
   }
 }
+
+// ---- training-time augmentation (ovla.h: ovla_image_augment) --------------------------------------------------------------------------
+constexpr int AUG_BLOCKS = 49;   // blocks per image in pass A (1024 pixels each at 224 x 224); partial sums are combined in this fixed order
+struct ImageAugParams {
+  const uint8_t* src; bf16_bits* dst; const float* params; float* tmp; double* partial;
+  int n_img, H, W, out, mask; float mean[6], stdv[6];
+};
+
+// pass A: u8 -> float, crop-and-resize, brightness; fp32 intermediate + per-block channel sums (fp64, fixed tree order)
+__global__ __launch_bounds__(256) void image_aug_a_kernel(const ImageAugParams p) {
+#pragma clang fp contract(off)
+  __shared__ double red[3][256];
+  const int img = blockIdx.y, blk = blockIdx.x;
+  const int npix = p.out * p.out, per_blk = (npix + AUG_BLOCKS - 1) / AUG_BLOCKS;
+  const float* prm = p.params + (int64_t)img * 8;
+  const uint8_t* im = p.src + (int64_t)img * p.H * p.W * 3;
+  const float y1 = prm[0], x1 = prm[1], y2 = prm[2], x2 = prm[3], bdelta = prm[4];
+  const float hy = (float)(p.H - 1), hx = (float)(p.W - 1), od = (float)(p.out - 1);
+  const float sy0 = y2 - y1, sx0 = x2 - x1;
+  const float sy1 = sy0 * hy, sx1 = sx0 * hx;
+  const float ystep = sy1 / od, xstep = sx1 / od;
+  const float ybase = y1 * hy, xbase = x1 * hx;
+  double acc[3] = {0.0, 0.0, 0.0};
+  const int end = (blk + 1) * per_blk < npix ? (blk + 1) * per_blk : npix;
+  for (int pix = blk * per_blk + threadIdx.x; pix < end; pix += 256) {
+    const int oy = pix / p.out, ox = pix - oy * p.out;
+    float v[3];
+    if (p.mask & 1) {
+      const float ty = (float)oy * ystep, tx = (float)ox * xstep;
+      const float ys = ybase + ty, xs = xbase + tx;
+      if (ys < 0.0f || ys > hy || xs < 0.0f || xs > hx) {
+        v[0] = v[1] = v[2] = 0.0f;    // extrapolation_value
+      } else {
+        const float fy = floorf(ys), fx = floorf(xs);
+        const int y0 = (int)fy, x0 = (int)fx, yb = (int)ceilf(ys), xr = (int)ceilf(xs);
+        const float wy = ys - fy, wx = xs - fx;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float tl = (float)im[((int64_t)y0 * p.W + x0) * 3 + c] / 255.0f, tr = (float)im[((int64_t)y0 * p.W + xr) * 3 + c] / 255.0f;
+          const float bl = (float)im[((int64_t)yb * p.W + x0) * 3 + c] / 255.0f, br = (float)im[((int64_t)yb * p.W + xr) * 3 + c] / 255.0f;
+          const float dt = tr - tl, db = br - bl;
+          const float pt = dt * wx, pb = db * wx;
+          const float top = tl + pt, bot = bl + pb;
+          const float dv = bot - top;
+          const float pv = dv * wy;
+          v[c] = top + pv;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = v[c] < 0.0f ? 0.0f : (v[c] > 1.0f ? 1.0f : v[c]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = (float)im[((int64_t)oy * p.W + ox) * 3 + c] / 255.0f;
+    }
+    if (p.mask & 2) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float t = v[c] + bdelta;
+        v[c] = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+      }
+    }
+    float* o = p.tmp + ((int64_t)img * npix + pix) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o[c] = v[c]; acc[c] += (double)v[c]; }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) red[c][threadIdx.x] = acc[c];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) p.partial[((int64_t)img * AUG_BLOCKS + blk) * 3 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// adjust_saturation_op.cc (CPU kernel): internal::rgb_to_hsv / hsv_to_rgb, operation for operation (its `2.0 / 6.0` are double constants)
+__device__ __forceinline__ void tf_rgb_to_hsv(float r, float g, float b, float& h, float& s, float& v) {
+#pragma clang fp contract(off)
+  const float vv = fmaxf(r, fmaxf(g, b));
+  const float range = vv - fminf(r, fminf(g, b));
+  s = vv > 0.0f ? range / vv : 0.0f;
+  const float six_range = 6.0f * range;
+  const float norm = 1.0f / six_range;
+  float hh;
+  if (r == vv) { const float d = g - b; hh = norm * d; }
+  else if (g == vv) { const float d = b - r; const float t = norm * d; hh = (float)((double)t + 2.0 / 6.0); }
+  else { const float d = r - g; const float t = norm * d; hh = (float)((double)t + 4.0 / 6.0); }
+  if (range <= 0.0f) hh = 0.0f;
+  if (hh < 0.0f) hh = hh + 1.0f;
+  v = vv; h = hh;
+}
+__device__ __forceinline__ void tf_hsv_to_rgb(float h, float s, float v, float& r, float& g, float& b) {
+#pragma clang fp contract(off)
+  const float c = s * v;
+  const float m = v - c;
+  const float dh = h * 6.0f;
+  const int cat = (int)dh;
+  float fmodu = dh;
+  while (fmodu <= 0.0f) fmodu += 2.0f;
+  while (fmodu >= 2.0f) fmodu -= 2.0f;
+  const float a1 = fmodu - 1.0f;
+  const float a2 = 1.0f - fabsf(a1);
+  const float x = c * a2;
+  float rr = 0.0f, gg = 0.0f, bb = 0.0f;
+  switch (cat) {
+    case 0: rr = c; gg = x; break;
+    case 1: rr = x; gg = c; break;
+    case 2: gg = c; bb = x; break;
+    case 3: gg = x; bb = c; break;
+    case 4: rr = x; bb = c; break;
+    case 5: rr = c; bb = x; break;
+    default: break;
+  }
+  r = rr + m; g = gg + m; b = bb + m;
+}
+// adjust_hue_op.cc (CPU kernel): rgb_to_hv_range / hv_range_to_rgb
+__device__ __forceinline__ void tf_adjust_hue(float& r, float& g, float& b, float delta_h) {
+#pragma clang fp contract(off)
+  float v_min, v_mid, v_max; int cat;
+  if (r < g) {
+    if (b < r) { v_max = g; v_mid = r; v_min = b; cat = 1; }
+    else if (b > g) { v_max = b; v_mid = g; v_min = r; cat = 3; }
+    else { v_max = g; v_mid = b; v_min = r; cat = 2; }
+  } else {
+    if (b < g) { v_max = r; v_mid = g; v_min = b; cat = 0; }
+    else if (b > r) { v_max = b; v_mid = r; v_min = g; cat = 4; }
+    else { v_max = r; v_mid = b; v_min = g; cat = 5; }
+  }
+  float h;
+  if (v_max == v_min) {
+    h = 0.0f;
+  } else {
+    const float num = v_mid - v_min, den = v_max - v_min;
+    const float ratio = num / den;
+    const float one_m = 1.0f - ratio;
+    h = (float)cat + ((cat & 1) == 0 ? ratio : one_m);
+  }
+  const float dd = delta_h * 6.0f;
+  h = h + dd;
+  while (h < 0.0f) h += 6.0f;
+  while (h >= 6.0f) h -= 6.0f;
+  const int c2 = (int)h;
+  float ratio = h - (float)c2;
+  if ((c2 & 1) != 0) ratio = 1.0f - ratio;
+  const float span = v_max - v_min;
+  const float pr = ratio * span;
+  const float mid = v_min + pr;
+  switch (c2) {
+    case 0: r = v_max; g = mid; b = v_min; break;
+    case 1: r = mid; g = v_max; b = v_min; break;
+    case 2: r = v_min; g = v_max; b = mid; break;
+    case 3: r = v_min; g = mid; b = v_max; break;
+    case 4: r = mid; g = v_min; b = v_max; break;
+    default: r = v_max; g = v_min; b = mid; break;
+  }
+}
+
+// pass B: contrast (needs the image mean), saturation, hue, uint8 re-quantisation, both normalisations
+__global__ __launch_bounds__(256) void image_aug_b_kernel(const ImageAugParams p) {
+#pragma clang fp contract(off)
+  __shared__ float mean_s[3];
+  const int img = blockIdx.y;
+  const int npix = p.out * p.out;
+  if (threadIdx.x < 3) {
+    double s = 0.0;
+    for (int k = 0; k < AUG_BLOCKS; ++k) s += p.partial[((int64_t)img * AUG_BLOCKS + k) * 3 + threadIdx.x];
+    mean_s[threadIdx.x] = (float)(s / (double)npix);
+  }
+  __syncthreads();
+  const float* prm = p.params + (int64_t)img * 8;
+  const float cf = prm[5], sf = prm[6], hd = prm[7];
+  const int64_t plane = (int64_t)npix;
+  for (int pix = blockIdx.x * 256 + threadIdx.x; pix < npix; pix += gridDim.x * 256) {
+    const float* t = p.tmp + ((int64_t)img * npix + pix) * 3;
+    float v[3] = {t[0], t[1], t[2]};
+    if (p.mask & 4) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float d = v[c] - mean_s[c];
+        const float e = d * cf;
+        const float f = e + mean_s[c];
+        v[c] = f < 0.0f ? 0.0f : (f > 1.0f ? 1.0f : f);
+      }
+    }
+    if (p.mask & 8) {
+      float h, s, vv;
+      tf_rgb_to_hsv(v[0], v[1], v[2], h, s, vv);
+      const float s2 = s * sf;
+      s = fminf(1.0f, fmaxf(0.0f, s2));
+      tf_hsv_to_rgb(h, s, vv, v[0], v[1], v[2]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = v[c] < 0.0f ? 0.0f : (v[c] > 1.0f ? 1.0f : v[c]);
+    }
+    if (p.mask & 16) {
+      tf_adjust_hue(v[0], v[1], v[2], hd);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = v[c] < 0.0f ? 0.0f : (v[c] > 1.0f ? 1.0f : v[c]);
+    }
+    bf16_bits* o = p.dst + (int64_t)img * 6 * plane + pix;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float scaled = v[c] * 255.0f;
+      const uint8_t q = (uint8_t)scaled;                  // tf.cast(image * 255, tf.uint8): truncation
+      const float x = (float)q / 255.0f;
+      const float d0 = x - p.mean[c], d1 = x - p.mean[3 + c];
+      o[c * plane] = f2bf(d0 / p.stdv[c]);
+      o[(3 + c) * plane] = f2bf(d1 / p.stdv[3 + c]);
+    }
+  }
+}
 }  // namespace
+
+extern "C" int64_t ovla_image_augment_workspace_bytes(int32_t n_img, int32_t out) {
+  if (n_img <= 0 || out <= 0) return 0;
+  const int64_t tmp = (((int64_t)n_img * out * out * 3 * 4) + 15) / 16 * 16;
+  return tmp + (int64_t)n_img * AUG_BLOCKS * 3 * 8;
+}
+
+extern "C" int ovla_image_augment(const ovla_image_augment_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->src && a->dst && a->params && a->workspace, "ovla_image_augment: null pointer");
+  OVLA_REQUIRE(a->n_img > 0 && a->n_img <= 65535 && a->H > 1 && a->W > 1 && a->out > 1, "ovla_image_augment: bad shape %d x %d x %d -> %d", a->n_img, a->H, a->W, a->out);
+  OVLA_REQUIRE((a->ops_mask & ~31) == 0, "ovla_image_augment: ops_mask %d has unknown bits", a->ops_mask);
+  OVLA_REQUIRE((a->ops_mask & 1) || (a->H == a->out && a->W == a->out), "ovla_image_augment: without crop-and-resize the input must already be %d x %d", a->out, a->out);
+  OVLA_REQUIRE(aligned16(a->workspace) && a->workspace_bytes >= ovla_image_augment_workspace_bytes(a->n_img, a->out),
+               "ovla_image_augment: needs a 16-byte aligned workspace of %lld bytes", (long long)ovla_image_augment_workspace_bytes(a->n_img, a->out));
+  ImageAugParams p;
+  p.src = (const uint8_t*)a->src; p.dst = (bf16_bits*)a->dst; p.params = a->params;
+  p.tmp = (float*)a->workspace;
+  p.partial = (double*)((char*)a->workspace + (((int64_t)a->n_img * a->out * a->out * 3 * 4) + 15) / 16 * 16);
+  p.n_img = a->n_img; p.H = a->H; p.W = a->W; p.out = a->out; p.mask = a->ops_mask;
+  for (int i = 0; i < 6; ++i) {
+    OVLA_REQUIRE(a->std[i] != 0.0f, "ovla_image_augment: std[%d] == 0", i);
+    p.mean[i] = a->mean[i]; p.stdv[i] = a->std[i];
+  }
+  hipLaunchKernelGGL(image_aug_a_kernel, dim3(AUG_BLOCKS, a->n_img), dim3(256), 0, stream, p);
+  OVLA_CHECK_LAUNCH("ovla_image_augment(a)");
+  hipLaunchKernelGGL(image_aug_b_kernel, dim3(cdiv(a->out * a->out, 1024), a->n_img), dim3(256), 0, stream, p);
+  OVLA_CHECK_LAUNCH("ovla_image_augment(b)");
+  return OVLA_OK;
+}
 
 extern "C" int ovla_norm_fwd(const ovla_norm_fwd_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -432,6 +432,30 @@ def image_prep(images_u8, *, crop: bool, crop_scale: float = 0.9, out_size: int 
     return out
 
 
+AUG_CROP, AUG_BRIGHTNESS, AUG_CONTRAST, AUG_SATURATION, AUG_HUE = 1, 2, 4, 8, 16
+AUG_ALL = 31
+
+
+def image_augment(images_u8, params, *, ops_mask: int = AUG_ALL, out_size: int = 224,
+                  mean=(0.485, 0.456, 0.406, 0.5, 0.5, 0.5), std=(0.229, 0.224, 0.225, 0.5, 0.5, 0.5)):
+    """Training-time frames: uint8 [n, H, W, 3] + fp32 params [n, 8] (both on the device) -> bf16 [n, 6, out, out]: dlimp's
+    augment_image ops (crop-and-resize box, brightness, contrast, saturation, hue; `ops_mask` selects them), uint8 re-quantisation
+    and both backbones' normalisations (ovla.h: ovla_image_augment).  ops_mask = 0 is the evaluation path."""
+    assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3 and images_u8.is_contiguous() and images_u8.is_cuda
+    n, H, W, _ = images_u8.shape
+    assert params.dtype == torch.float32 and tuple(params.shape) == (n, 8) and params.is_contiguous() and params.device == images_u8.device
+    out = torch.empty((n, 6, out_size, out_size), dtype=BF16, device=images_u8.device)
+    wsb = int(_lib.lib().ovla_image_augment_workspace_bytes(n, out_size))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=images_u8.device)
+    g = STRUCTS["ovla_image_augment_args"]()
+    g.src, g.dst, g.params, g.workspace, g.workspace_bytes = images_u8.data_ptr(), out.data_ptr(), params.data_ptr(), ws.data_ptr(), wsb
+    g.n_img, g.H, g.W, g.out, g.ops_mask = n, H, W, out_size, int(ops_mask)
+    for i in range(6):
+        g.mean[i], g.std[i] = mean[i], std[i]
+    _lib.call("ovla_image_augment", g, _stream())
+    return out
+
+
 def assemble_multimodal(ids, labels, table, patches, *, A, noisy=None, ignore_index=-100, action_token_begin=31743, action_dim=7):
     """ids/labels int64 [B,L]; table bf16 [V,D]; patches bf16 [B,P,D] -> (out [B,P+L,D], action_rows int32 [B,A]:
     flattened row of the hidden state that predicts each action slot)."""

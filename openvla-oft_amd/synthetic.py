@@ -66,3 +66,29 @@ def make_batch(batch_size: int = 8, *, seed: int = 0, prompt_lens=None, chunk: i
     inst = [make_instance(rng, prompt_len=tp, chunk=chunk, action_dim=action_dim, proprio_dim=proprio_dim, num_images=num_images,
                           image_size=image_size) for tp in prompt_lens]
     return collate(inst)
+
+
+def write_synthetic_episodes(root, dataset_name: str = "libero_spatial_no_noops", n_episodes: int = 4, *, seed: int = 0, min_len: int = 40,
+                             max_len: int = 60, image_size: int = 224, unlabeled_every: int = 0):
+    """A small LIBERO-shaped episode store (the layout of prismatic/vla/datasets/rlds_free.py): smooth random frames, 8-d state, 7-d
+    raw actions with the gripper in {-1, +1} as the LIBERO RLDS builder stores it.  Stands in for the real demonstrations, which
+    cannot be fetched offline."""
+    import importlib
+    rlds_free = importlib.import_module(__package__ + ".prismatic.vla.datasets.rlds_free")
+    rng = np.random.default_rng(seed)
+    tasks = ["pick up the black bowl and place it on the plate", "put the cream cheese in the bowl", "turn on the stove", "open the top drawer"]
+    for e in range(n_episodes):
+        T = int(rng.integers(min_len, max_len + 1))
+        base = rng.integers(0, 256, size=(2, image_size // 8, image_size // 8, 3)).astype(np.float32)
+        frames = []
+        for cam in range(2):
+            up = np.kron(base[cam], np.ones((8, 8, 1), np.float32))
+            drift = rng.normal(0, 6, size=(T, 1, 1, 3)).astype(np.float32).cumsum(axis=0)
+            frames.append(np.clip(up[None] + drift + rng.normal(0, 3, size=(T, image_size, image_size, 3)), 0, 255).astype(np.uint8))
+        action = rng.normal(0, 0.3, size=(T, 7)).astype(np.float32)
+        action[:, -1] = np.where(np.sin(np.arange(T) / 7.0 + e) > 0, 1.0, -1.0)
+        state = rng.normal(0, 0.5, size=(T, 8)).astype(np.float32).cumsum(axis=0) * 0.05
+        lang = "" if (unlabeled_every and (e + 1) % unlabeled_every == 0) else tasks[e % len(tasks)]
+        rlds_free.write_episode(root, dataset_name, e, arrays={"image": frames[0], "wrist_image": frames[1], "state": state, "action": action},
+                                language_instruction=lang)
+    return root

@@ -202,8 +202,11 @@ def load_training_checkpoint(ckpt: Path, log_step: Optional[int], engine: VLAEng
 
 
 def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state_dict: Optional[Dict[str, torch.Tensor]] = None,
-             dataset: Optional[Iterable[dict]] = None, dataset_statistics: Optional[dict] = None, log=print) -> Dict[str, list]:
-    """finetune.py:763-1154.  Returns the logged metric history."""
+             dataset: Optional[Iterable[dict]] = None, dataset_statistics: Optional[dict] = None, log=print, tokenizer=None) -> Dict[str, list]:
+    """finetune.py:763-1154.  Returns the logged metric history.  Data source, in this order: `dataset` (any iterable of collated
+    batches); an episode store at `cfg.data_root_dir / cfg.dataset_name` (prismatic/vla/datasets/rlds_free.py: the reference's
+    RLDSDataset + RLDSBatchTransform + collator, finetune.py:981-1016, with the frames augmented and normalised on the device --
+    needs `tokenizer(text) -> ids` or tokenizer files under `cfg.vla_path`); otherwise seeded synthetic batches of the recipe's shape."""
     assert cfg.use_lora, "Only LoRA fine-tuning is supported. Please set --use_lora=True!"
     assert not (cfg.use_l1_regression and cfg.use_diffusion), "Cannot do both L1 regression and diffusion. Please pick one of them!"
     if not (cfg.use_l1_regression or cfg.use_diffusion):
@@ -242,6 +245,27 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
             f"{len(info['missing'])} trainable tensors kept at their initial values")
     reducer = GradReducer(engine.stores, world) if world > 1 else None
     engine.attach_reducer(reducer, overlap=cfg.grad_accumulation_steps == 1 and os.environ.get("OVLA_DP_OVERLAP", "1") != "0")   # overlap only when every backward ends a step
+    if dataset is None and (Path(cfg.data_root_dir) / cfg.dataset_name).is_dir():
+        from ..prismatic.vla import datasets as D
+        from ..prismatic.vla.action_tokenizer import ActionTokenizer
+
+        if tokenizer is None:
+            from transformers import AutoTokenizer   # tokenizer files inside the checkpoint directory
+
+            tok = AutoTokenizer.from_pretrained(cfg.vla_path)
+            tokenizer = lambda text: tok(text, add_special_tokens=True).input_ids  # noqa: E731
+        vocab = type("Vocab", (), {"vocab_size": model_config.vocab - model_config.pad_to_multiple_of})()   # 32000 (constants.py / modeling_prismatic.py:732)
+        side = model_config.dino.image_size
+        train_dataset = D.EpisodeDataset(cfg.data_root_dir, cfg.dataset_name,
+                                         D.RLDSBatchTransform(ActionTokenizer(vocab), tokenizer, use_wrist_image=cfg.num_images_in_input > 1,
+                                                              use_proprio=cfg.use_proprio),
+                                         resize_resolution=(side, side), shuffle_buffer_size=cfg.shuffle_buffer_size, image_aug=cfg.image_aug,
+                                         seed=7, rank=rank, world_size=world)
+        if dataset_statistics is None:
+            dataset_statistics = train_dataset.dataset_statistics    # saved next to every checkpoint (finetune.py:1003-1005)
+        collator = D.DeviceCollator(2048, model_config.pad_token_id, device=dev, image_aug=cfg.image_aug, seed=1000 + rank, image_size=side)
+        dataset = D.batches(train_dataset, collator, cfg.batch_size)
+        log(f"[finetune] episode store {cfg.data_root_dir / cfg.dataset_name}: {len(train_dataset)} frames, image_aug={cfg.image_aug}")
     if dataset is None:
         def synthetic_stream():
             step = 0
