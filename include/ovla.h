@@ -235,6 +235,21 @@ int ovla_im2col(const ovla_im2col_args* a, void* stream);
 typedef struct { const void* src; void* dst; int32_t n_img, H, W, out, crop; float crop_scale; float mean[6]; float std[6]; } ovla_image_prep_args;
 int ovla_image_prep(const ovla_image_prep_args* a, void* stream);
 
+/* Separable resampling with per-output-pixel spans (TF 2.15 `scale_and_translate_op.cc`, the kernel behind
+ * tf.image.resize(method="lanczos3", antialias=True) that experiments/robot/openvla_utils.py:516-540 `resize_image_for_policy` and
+ * dlimp's `resize_image` (rlds/obs_transforms.py:83) call): rows first into an fp32 intermediate [n, out_h, W, 3], then columns;
+ * out = sum_k weights[o, k] * in[starts[o] + k] accumulated in span order from 0, each multiply and add rounded on its own; then
+ * tf.round (half to even), clip to [0, 255], uint8.  The spans (starts int32 [out], weights fp32 [out, span]) are computed by the host
+ * (image_prep.lanczos3_spans) and passed as device arrays.  The reference's JPEG encode/decode round trip before the resize is NOT
+ * reproduced (libjpeg's lossy codec); PARITY UNPINNED against TensorFlow, bit-compared with oracle/data_oracle.py. */
+typedef struct {
+  const void* src; void* dst; void* workspace; int64_t workspace_bytes;
+  const int32_t* row_starts; const float* row_weights; const int32_t* col_starts; const float* col_weights;
+  int32_t n_img, H, W, out_h, out_w, row_span, col_span;
+} ovla_image_resize_args;
+int64_t ovla_image_resize_workspace_bytes(int32_t n_img, int32_t W, int32_t out_h);
+int ovla_image_resize(const ovla_image_resize_args* a, void* stream);
+
 /* Training-time image path as two launches (replaces the TF/dlimp frame transform + PIL/torchvision processor of the reference's data
  * loader: prismatic/vla/datasets/rlds/obs_transforms.py:18-45 `augment` -> dlimp `augment_image` with the kwargs of
  * prismatic/vla/datasets/datasets.py:159-174, then prismatic/extern/hf/processing_prismatic.py:128-145 `apply_transform`).

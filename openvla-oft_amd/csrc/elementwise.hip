@@ -889,6 +889,72 @@ __global__ __launch_bounds__(256) void image_aug_b_kernel(const ImageAugParams p
 }
 }  // namespace
 
+namespace {
+struct ImageResizeParams {
+  const uint8_t* src; uint8_t* dst; float* tmp; const int* row_starts; const float* row_weights; const int* col_starts; const float* col_weights;
+  int n_img, H, W, out_h, out_w, row_span, col_span;
+};
+__global__ __launch_bounds__(256) void image_resize_rows_kernel(const ImageResizeParams p) {
+#pragma clang fp contract(off)
+  const int64_t row_elems = (int64_t)p.W * 3, total = (int64_t)p.n_img * p.out_h * row_elems;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int e = (int)(idx % row_elems), y = (int)((idx / row_elems) % p.out_h), img = (int)(idx / (row_elems * p.out_h));
+    const int st = p.row_starts[y];
+    const int real = (st + p.row_span < p.H ? st + p.row_span : p.H) - st;
+    const uint8_t* in = p.src + ((int64_t)img * p.H + st) * row_elems + e;
+    const float* w = p.row_weights + (int64_t)y * p.row_span;
+    float acc = 0.0f;
+    for (int k = 0; k < real; ++k) {
+      const float t = (float)in[(int64_t)k * row_elems] * w[k];
+      acc = acc + t;
+    }
+    p.tmp[idx] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void image_resize_cols_kernel(const ImageResizeParams p) {
+#pragma clang fp contract(off)
+  const int64_t total = (int64_t)p.n_img * p.out_h * p.out_w * 3;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx % 3), x = (int)((idx / 3) % p.out_w);
+    const int64_t row = idx / ((int64_t)3 * p.out_w);     // img * out_h + y
+    const int st = p.col_starts[x];
+    const int real = (st + p.col_span < p.W ? st + p.col_span : p.W) - st;
+    const float* in = p.tmp + (row * p.W + st) * 3 + c;
+    const float* w = p.col_weights + (int64_t)x * p.col_span;
+    float acc = 0.0f;
+    for (int k = 0; k < real; ++k) {
+      const float t = in[k * 3] * w[k];
+      acc = acc + t;
+    }
+    float r = rintf(acc);                                   // tf.round: half to even
+    r = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
+    p.dst[idx] = (uint8_t)r;
+  }
+}
+}  // namespace
+
+extern "C" int64_t ovla_image_resize_workspace_bytes(int32_t n_img, int32_t W, int32_t out_h) {
+  return (n_img > 0 && W > 0 && out_h > 0) ? (int64_t)n_img * out_h * W * 3 * 4 : 0;
+}
+
+extern "C" int ovla_image_resize(const ovla_image_resize_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->src && a->dst && a->workspace && a->row_starts && a->row_weights && a->col_starts && a->col_weights, "ovla_image_resize: null pointer");
+  OVLA_REQUIRE(a->n_img > 0 && a->H > 0 && a->W > 0 && a->out_h > 0 && a->out_w > 0, "ovla_image_resize: bad shape %d x %d x %d -> %d x %d", a->n_img, a->H, a->W, a->out_h, a->out_w);
+  OVLA_REQUIRE(a->row_span > 0 && a->row_span <= a->H && a->col_span > 0 && a->col_span <= a->W, "ovla_image_resize: span sizes %d / %d exceed the image", a->row_span, a->col_span);
+  OVLA_REQUIRE(a->workspace_bytes >= ovla_image_resize_workspace_bytes(a->n_img, a->W, a->out_h), "ovla_image_resize: needs a workspace of %lld bytes",
+               (long long)ovla_image_resize_workspace_bytes(a->n_img, a->W, a->out_h));
+  ImageResizeParams p;
+  p.src = (const uint8_t*)a->src; p.dst = (uint8_t*)a->dst; p.tmp = (float*)a->workspace;
+  p.row_starts = a->row_starts; p.row_weights = a->row_weights; p.col_starts = a->col_starts; p.col_weights = a->col_weights;
+  p.n_img = a->n_img; p.H = a->H; p.W = a->W; p.out_h = a->out_h; p.out_w = a->out_w; p.row_span = a->row_span; p.col_span = a->col_span;
+  hipLaunchKernelGGL(image_resize_rows_kernel, dim3(grid_for((int64_t)a->n_img * a->out_h * a->W * 3)), dim3(256), 0, stream, p);
+  OVLA_CHECK_LAUNCH("ovla_image_resize(rows)");
+  hipLaunchKernelGGL(image_resize_cols_kernel, dim3(grid_for((int64_t)a->n_img * a->out_h * a->out_w * 3)), dim3(256), 0, stream, p);
+  OVLA_CHECK_LAUNCH("ovla_image_resize(cols)");
+  return OVLA_OK;
+}
+
 extern "C" int64_t ovla_image_augment_workspace_bytes(int32_t n_img, int32_t out) {
   if (n_img <= 0 || out <= 0) return 0;
   const int64_t tmp = (((int64_t)n_img * out * out * 3 * 4) + 15) / 16 * 16;

@@ -1,5 +1,6 @@
 """Host-side image preparation of the inference glue, without TensorFlow / torchvision.
 
+  resize_image_for_policy  experiments/robot/openvla_utils.py:516-540  (lanczos3 + antialias resize on the device; no JPEG round trip)
   center_crop_image        experiments/robot/openvla_utils.py:542-622  (tf.image.crop_and_resize of the central
                            sqrt(0.9) x sqrt(0.9) box back to 224 x 224, bilinear, on float [0,1], back to uint8)
   apply_transform          prismatic/extern/hf/processing_prismatic.py:128-145 (per-backbone to_tensor + normalise, channel
@@ -53,14 +54,77 @@ def center_crop_image(image_u8: np.ndarray, crop_scale: float = 0.9, out_size: i
     return (np.clip(out, f(0), f(1)) * f(255.5)).astype(np.uint8)
 
 
+_SPAN_CACHE = {}
+
+
+def lanczos3_spans(in_size: int, out_size: int):
+    """The per-output-pixel sample spans of tf.image.resize(method="lanczos3", antialias=True) along one axis, after TF 2.15's
+    scale_and_translate_op.cc `ComputeSpansCore` (float32 throughout): scale = out / in, kernel widened by max(1 / scale, 1) when
+    downsampling, span = [ceil(s - r k - 0.5), floor(s + r k - 0.5)] clamped to the image, weights = lanczos3((i + 0.5 - s) / k)
+    normalised to sum 1.  -> (starts int32 [out], weights float32 [out, span_size]); PARITY UNPINNED against TensorFlow."""
+    key = (in_size, out_size)
+    if key in _SPAN_CACHE:
+        return _SPAN_CACHE[key]
+    f = np.float32
+    radius = f(3.0)
+    scale = f(f(out_size) / f(in_size))
+    inv_scale = f(1.0 / np.float64(scale))
+    kernel_scale = max(inv_scale, f(1.0))
+    span_size = min(2 * int(np.ceil(radius * kernel_scale)) + 1, in_size)
+    inv_ks = f(f(1.0) / kernel_scale)
+    x = np.arange(out_size, dtype=f)
+    sample = ((x + f(0.5)) * inv_scale + f(-inv_scale * f(0.0))).astype(f)
+    rk = f(radius * kernel_scale)
+    start = np.clip(np.ceil((sample - rk).astype(f) - f(0.5)).astype(np.int64), 0, in_size - 1)
+    end = np.clip(np.floor((sample + rk).astype(f) - f(0.5)).astype(np.int64), 0, in_size - 1) + 1
+    k = np.arange(span_size)[None, :]
+    src = start[:, None] + k
+    pos = np.abs((((src.astype(f) + f(0.5)) - sample[:, None]).astype(f) * inv_ks).astype(f))
+    pi = f(3.14159265359)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        px = (pi * pos).astype(f)
+        num = ((radius * np.sin(px).astype(f)).astype(f) * np.sin((px / radius).astype(f)).astype(f)).astype(f)
+        den = (((pi * pi).astype(f) * pos).astype(f) * pos).astype(f)
+        w = (num / den).astype(f)
+    w = np.where(pos <= f(1e-3), f(1.0), w)
+    w = np.where(pos > radius, f(0.0), w)
+    w = np.where(src < end[:, None], w, f(0.0)).astype(f)
+    total = np.zeros(out_size, f)
+    for j in range(span_size):                       # TF accumulates the weight sum in span order
+        total = (total + w[:, j]).astype(f)
+    ok = np.abs(total) >= f(1000.0) * np.finfo(f).tiny
+    w = np.where(ok[:, None], (w * (f(1.0) / np.where(ok, total, f(1.0))).astype(f)[:, None]).astype(f), f(0.0)).astype(f)
+    outside = (sample < 0) | (sample > f(in_size))
+    w[outside] = 0
+    start = np.where(outside, 0, start)
+    _SPAN_CACHE[key] = (start.astype(np.int32), np.ascontiguousarray(w))
+    return _SPAN_CACHE[key]
+
+
+def resize_image_for_policy(img: np.ndarray, resize_size, device=None) -> np.ndarray:
+    """experiments/robot/openvla_utils.py:516-540 without its JPEG encode/decode round trip (libjpeg's lossy codec is not
+    restatable here): tf.image.resize(lanczos3, antialias=True) -> round -> clip -> uint8, on the device
+    (ovla_image_resize).  img uint8 [H, W, 3] -> uint8 [h, w, 3]."""
+    import importlib
+
+    ops = importlib.import_module(__package__ + ".ops")      # the HIP library: required
+    assert isinstance(resize_size, (int, tuple))
+    oh, ow = (resize_size, resize_size) if isinstance(resize_size, int) else resize_size
+    check_image_format(img)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    spans = [tuple(torch.from_numpy(a).to(dev) for a in lanczos3_spans(n_in, n_out)) for n_in, n_out in ((img.shape[0], oh), (img.shape[1], ow))]
+    out = ops.image_resize(torch.from_numpy(np.ascontiguousarray(img))[None].to(dev), spans[0], spans[1])
+    return out[0].cpu().numpy()
+
+
 def prepare_images_for_vla(images, cfg):
-    """experiments/robot/openvla_utils.py:678-708.  Inputs that are not 224x224 would need the reference's
-    JPEG round-trip + lanczos3 resize (TF); that branch is not available offline and raises."""
+    """experiments/robot/openvla_utils.py:678-708: frames that are not 224 x 224 are resized like the training pipeline's
+    (lanczos3, antialias; the reference's JPEG round trip before it is not reproduced), then center-cropped if configured."""
     out = []
     for image in images:
         check_image_format(image)
         if image.shape != (OPENVLA_IMAGE_SIZE, OPENVLA_IMAGE_SIZE, 3):
-            raise NotImplementedError("resize_image_for_policy (TF jpeg + lanczos3) is not available in this port; pass 224x224 images")
+            image = resize_image_for_policy(image, OPENVLA_IMAGE_SIZE)
         out.append(center_crop_image(image) if cfg.center_crop else image)
     return out
 

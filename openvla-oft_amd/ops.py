@@ -432,6 +432,28 @@ def image_prep(images_u8, *, crop: bool, crop_scale: float = 0.9, out_size: int 
     return out
 
 
+def image_resize(images_u8, row_spans, col_spans):
+    """uint8 [n, H, W, 3] (device) -> uint8 [n, out_h, out_w, 3]: separable span resampling (ovla.h: ovla_image_resize; TF's
+    scale_and_translate kernel, rows first).  `*_spans` = (starts int32 [out], weights fp32 [out, span]) on the device
+    (image_prep.lanczos3_spans)."""
+    assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3 and images_u8.is_contiguous() and images_u8.is_cuda
+    n, H, W, _ = images_u8.shape
+    (rs, rw), (cs, cw) = row_spans, col_spans
+    for st, wt in ((rs, rw), (cs, cw)):
+        assert st.dtype == torch.int32 and wt.dtype == torch.float32 and wt.dim() == 2 and wt.shape[0] == st.shape[0] and st.is_cuda and wt.is_cuda
+        assert st.is_contiguous() and wt.is_contiguous()
+    oh, ow = rs.shape[0], cs.shape[0]
+    out = torch.empty((n, oh, ow, 3), dtype=torch.uint8, device=images_u8.device)
+    wsb = int(_lib.lib().ovla_image_resize_workspace_bytes(n, W, oh))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=images_u8.device)
+    g = STRUCTS["ovla_image_resize_args"]()
+    g.src, g.dst, g.workspace, g.workspace_bytes = images_u8.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb
+    g.row_starts, g.row_weights, g.col_starts, g.col_weights = rs.data_ptr(), rw.data_ptr(), cs.data_ptr(), cw.data_ptr()
+    g.n_img, g.H, g.W, g.out_h, g.out_w, g.row_span, g.col_span = n, H, W, oh, ow, rw.shape[1], cw.shape[1]
+    _lib.call("ovla_image_resize", g, _stream())
+    return out
+
+
 AUG_CROP, AUG_BRIGHTNESS, AUG_CONTRAST, AUG_SATURATION, AUG_HUE = 1, 2, 4, 8, 16
 AUG_ALL = 31
 

@@ -23,7 +23,8 @@ Differences by design (MI355X-first, documented in DESIGN.md):
     pairs instead of a 256k-frame shuffle buffer over a sequential TFRecord stream;
   * ranks take disjoint strides of that permutation (the reference lets every rank draw its own shuffled stream, finetune.py:1022);
   * crop-and-resize, colour jitter, uint8 re-quantisation and both backbones' normalisations run as two HIP launches per batch
-    (`ovla_image_augment`) on uint8 frames copied to HBM as they are -- the host never touches a float pixel;
+    (`ovla_image_augment`) on uint8 frames copied to HBM as they are -- the host never touches a float pixel; frames stored at
+    another resolution are first resized there too (`ovla_image_resize`: dlimp resize_image's lanczos3 + antialias);
   * random numbers come from numpy's PCG64 (TF's stateless Philox stream cannot be matched without TensorFlow): the augmentation
     DISTRIBUTIONS are the reference's, the draws are not.
 Parity: TensorFlow and dlimp are not installable here, so everything that is TF arithmetic is PARITY UNPINNED against TF itself and
@@ -385,10 +386,6 @@ class EpisodeDataset:
         for t in trajs:
             if not t["language_instruction"]:           # skip_unlabeled=True
                 continue
-            for key, arr in t["observation"].items():
-                if key.startswith("image_") and arr is not None and tuple(arr.shape[1:3]) != self.resize_resolution:
-                    raise NotImplementedError(f"{key} is {arr.shape[1:3]}, not {self.resize_resolution}: dlimp's lanczos3 resize is not part of this "
-                                              "port; store frames at the model resolution")
             t = normalize_action_and_proprio(t, stats, C.ACTION_PROPRIO_NORMALIZATION_TYPE)
             obs_idx, act_idx, _ = chunk_indices(t["action"].shape[0], 1, self.future)
             t["act_idx"] = act_idx
@@ -403,7 +400,7 @@ class EpisodeDataset:
     def frame(self, traj_i: int, step: int) -> Dict[str, Any]:
         """One flattened frame in the layout `dataset.as_numpy_iterator()` hands to RLDSBatchTransform (window_size = 1)."""
         t = self.trajs[traj_i]
-        obs = {k: (np.zeros((1, *self.resize_resolution, 3), np.uint8) if v is None else v[step:step + 1])
+        obs = {k: (np.zeros((1, *self.resize_resolution, 3), np.uint8) if v is None else v[step:step + 1])   # stored size; the collator resizes
                for k, v in t["observation"].items() if k.startswith("image_")}
         obs["proprio"] = t["observation"]["proprio"][step:step + 1]
         return {"observation": obs, "task": {"language_instruction": t["language_instruction"].encode()}, "action": t["action"][t["act_idx"][step]],
@@ -450,6 +447,12 @@ class DeviceCollator:
         params = sample_augment_params(self._rng, flat.shape[0], self.augment_kwargs) if self.image_aug else identity_augment_params(flat.shape[0])
         mask = augment_ops_mask(self.augment_kwargs) if self.image_aug else 0
         dev_frames = torch.from_numpy(flat).to(self.device, non_blocking=True)
+        if tuple(dev_frames.shape[1:3]) != (self.image_size, self.image_size):
+            # decode_and_resize (rlds/obs_transforms.py:48-99 -> dlimp resize_image: lanczos3, antialias, round, uint8) before the augmentation
+            from .... import image_prep
+
+            spans = [tuple(torch.from_numpy(a).to(self.device) for a in image_prep.lanczos3_spans(n, self.image_size)) for n in dev_frames.shape[1:3]]
+            dev_frames = ops.image_resize(dev_frames, spans[0], spans[1])
         pv = ops.image_augment(dev_frames, torch.from_numpy(params).to(self.device, non_blocking=True), ops_mask=mask, out_size=self.image_size)
         out = dict(pixel_values=pv.view(len(instances), 6 * n_img, pv.shape[-2], pv.shape[-1]), input_ids=input_ids,
                    attention_mask=input_ids.ne(self.pad_token_id), labels=labels,

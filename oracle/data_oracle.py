@@ -193,3 +193,61 @@ def pixel_values(img_u8, mean=(0.485, 0.456, 0.406, 0.5, 0.5, 0.5), std=(0.229, 
     a = ((x - m[:3, None, None]).astype(F) / s[:3, None, None]).astype(F)
     b = ((x - m[3:, None, None]).astype(F) / s[3:, None, None]).astype(F)
     return np.concatenate([a, b], axis=0)
+
+
+# ---- lanczos3 resize (scale_and_translate_op.cc, TF 2.15) -------------------------------------------------------------------------
+def lanczos3_kernel(x):
+    """LanczosKernelFunc(radius 3): float32, kPI = 3.14159265359f"""
+    x = abs(F(x))
+    if x > F(3):
+        return F(0)
+    if x <= F(1e-3):
+        return F(1)
+    pi = F(3.14159265359)
+    px = F(pi * x)
+    return F(F(F(F(3) * np.sin(px, dtype=F)) * np.sin(F(px / F(3)), dtype=F)) / F(F(F(pi * pi) * x) * x))
+
+
+def lanczos3_spans_loop(in_size: int, out_size: int):
+    """ComputeSpansCore, element by element (scale = out / in, translate = 0, antialias = True)."""
+    scale = F(F(out_size) / F(in_size))
+    inv_scale = F(1.0 / np.float64(scale))
+    ks = max(inv_scale, F(1))
+    span = min(2 * int(np.ceil(F(3) * ks)) + 1, in_size)
+    inv_ks = F(F(1) / ks)
+    starts, weights = np.zeros(out_size, np.int32), np.zeros((out_size, span), F)
+    for x in range(out_size):
+        s = F(F(F(x) + F(0.5)) * inv_scale + F(-inv_scale * F(0)))
+        if s < 0 or s > F(in_size):
+            continue
+        rk = F(F(3) * ks)
+        a = min(max(int(np.ceil(F(F(s - rk) - F(0.5)))), 0), in_size - 1)
+        b = min(max(int(np.floor(F(F(s + rk) - F(0.5)))), 0), in_size - 1) + 1
+        tmp, total = [], F(0)
+        for src in range(a, b):
+            w = lanczos3_kernel(F(F(F(F(src) + F(0.5)) - s) * inv_ks))
+            total = F(total + w)
+            tmp.append(w)
+        if abs(total) >= F(1000) * np.finfo(F).tiny:
+            inv = F(F(1) / total)
+            for j, w in enumerate(tmp):
+                weights[x, j] = F(w * inv)
+        starts[x] = a
+    return starts, weights
+
+
+def resize_lanczos3(img_u8, out_h: int, out_w: int):
+    """GatherRows then GatherColumns (sequential float32 accumulation from 0 in span order), tf.round, clip, uint8."""
+    H, W = img_u8.shape[:2]
+    rs, rw = lanczos3_spans_loop(H, out_h)
+    cs, cw = lanczos3_spans_loop(W, out_w)
+    x = img_u8.astype(F)
+    mid = np.zeros((out_h, W, 3), F)
+    for y in range(out_h):
+        for k in range(min(rs[y] + rw.shape[1], H) - rs[y]):
+            mid[y] = (mid[y] + (x[rs[y] + k] * rw[y, k]).astype(F)).astype(F)
+    out = np.zeros((out_h, out_w, 3), F)
+    for xo in range(out_w):
+        for k in range(min(cs[xo] + cw.shape[1], W) - cs[xo]):
+            out[:, xo] = (out[:, xo] + (mid[:, cs[xo] + k] * cw[xo, k]).astype(F)).astype(F)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)

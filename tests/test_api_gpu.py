@@ -92,8 +92,8 @@ def test_get_vla_action_glue(world):
         c = types.SimpleNamespace(center_crop=crop)
         host = torch.cat([ip.apply_transform(im)[None] for im in ip.prepare_images_for_vla(list(imgs), c)], dim=1).to(BF)
         assert torch.equal(utils.device_pixel_values(imgs, c).cpu(), host)
-    with pytest.raises(NotImplementedError, match="224x224"):
-        utils.device_pixel_values([np.zeros((256, 256, 3), np.uint8)], cfg)
+    # simulator-sized frames are resized on the device (lanczos3 + antialias; tests/test_data_path.py checks the arithmetic)
+    assert utils.device_pixel_values([np.zeros((256, 256, 3), np.uint8), obs["wrist_image"]], cfg).shape == (1, 12, 224, 224)
 
 
 def test_autograd_bridge_equals_fused_step(world):

@@ -138,8 +138,6 @@ def test_episode_dataset_frames_and_rank_partition(tmp_path):
         it = iter(D.RLDSDataset(tmp_path, "libero_spatial_no_noops", bt, resize_resolution=(32, 32), train=True, seed=3, rank=rank, world_size=2))
         seen.append([tuple(next(it)["actions"].reshape(-1)[:3]) for _ in range(len(ds) // 2)])
     assert len(set(seen[0]) & set(seen[1])) == 0 and len(set(seen[0]) | set(seen[1])) == 2 * (len(ds) // 2)
-    with pytest.raises(NotImplementedError):
-        D.RLDSDataset(tmp_path, "libero_spatial_no_noops", bt, resize_resolution=(224, 224))
     with pytest.raises(KeyError):
         D.RLDSDataset(tmp_path, "not_a_dataset", bt)
 
@@ -183,6 +181,22 @@ def test_oracle_image_ops_known_answers():
     assert np.all(bright == int(F(F(100) / F(255) + F(0.2)) * F(255)))
     pv = do.pixel_values(np.full((2, 2, 3), 255, np.uint8))
     assert np.allclose(pv[:3, 0, 0], (1 - np.array([0.485, 0.456, 0.406])) / np.array([0.229, 0.224, 0.225]), atol=1e-6) and np.allclose(pv[3:], 1.0)
+
+
+def test_lanczos3_spans():
+    """scale_and_translate_op.cc ComputeSpansCore: vectorised host code == element loop; weights of a span sum to 1; same-size is
+    the identity after rounding; kernel values at the known points."""
+    ip = load("openvla-oft_amd.image_prep")
+    for a, b in [(256, 224), (224, 224), (128, 224), (480, 224), (640, 224), (7, 5), (3, 9)]:
+        s, w = ip.lanczos3_spans(a, b)
+        s2, w2 = do.lanczos3_spans_loop(a, b)
+        assert np.array_equal(s, s2) and np.array_equal(w, w2) and np.allclose(w.sum(1), 1, atol=1e-6), (a, b)
+        assert w.shape[1] == min(2 * int(np.ceil(3 * max(a / b, 1))) + 1, a) and s.min() >= 0 and (s + 1 <= a).all()
+    assert do.lanczos3_kernel(0) == 1 and do.lanczos3_kernel(3.5) == 0 and abs(do.lanczos3_kernel(1)) < 1e-7 and abs(do.lanczos3_kernel(2)) < 1e-7
+    assert abs(do.lanczos3_kernel(0.5) - 3 * 1 * 0.5 / (np.pi ** 2 * 0.25)) < 1e-6
+    img = np.random.default_rng(0).integers(0, 256, (24, 24, 3), dtype=np.uint8)
+    assert np.array_equal(do.resize_lanczos3(img, 24, 24), img)
+    assert np.all(do.resize_lanczos3(np.full((32, 40, 3), 77, np.uint8), 16, 24) == 77)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------- GPU
@@ -264,6 +278,10 @@ def test_device_collator_batch_layout(tmp_path, ops, dev):
             assert torch.equal(batch["pixel_values"][i, 6 * j: 6 * j + 6].cpu(), want), (i, j)
     ev = R.DeviceCollator(2048, 32000, device=dev, image_aug=False)(inst)
     assert torch.equal(ev["pixel_values"][0, :6].cpu(), torch.from_numpy(do.pixel_values(inst[0]["image"])).to(BF))
+    # frames stored at another resolution are resized on the device first (dlimp resize_image), then augmented
+    small = R.DeviceCollator(2048, 32000, device=dev, image_aug=True, seed=11, image_size=96)(inst)
+    want = do.pixel_values(do.augment_image(do.resize_lanczos3(inst[0]["image"], 96, 96), params[0], 31, 96))
+    assert small["pixel_values"].shape == (3, 12, 96, 96) and torch.equal(small["pixel_values"][0, :6].cpu(), torch.from_numpy(want).to(BF))
 
 
 @pytest.mark.gpu
@@ -287,3 +305,34 @@ def test_finetune_reads_an_episode_store(tmp_path, dev):
     ck = list((tmp_path / "runs").glob("*--2_chkpt"))[0]
     stats = json.loads((ck / "dataset_statistics.json").read_text())
     assert stats["libero_spatial_no_noops"]["action"]["mask"] == [True] * 6 + [False] and stats["libero_spatial_no_noops"]["num_trajectories"] == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,oh,ow", [(256, 256, 224, 224), (128, 160, 224, 224), (480, 640, 224, 224), (224, 224, 224, 224), (50, 30, 20, 45)])
+def test_image_resize_matches_oracle_bit_for_bit(ops, dev, H, W, oh, ow):
+    """ovla_image_resize (lanczos3 + antialias, rows then columns, tf.round, uint8) == oracle/data_oracle.py resize_lanczos3."""
+    ip = load("openvla-oft_amd.image_prep")
+    img = _frames(np.random.default_rng(H + W), 2, H, W)
+    spans = [tuple(torch.from_numpy(a).to(dev) for a in ip.lanczos3_spans(n_in, n_out)) for n_in, n_out in ((H, oh), (W, ow))]
+    got = ops.image_resize(torch.from_numpy(img).to(dev), spans[0], spans[1]).cpu().numpy()
+    for i in range(2):
+        want = do.resize_lanczos3(img[i], oh, ow)
+        assert np.array_equal(got[i], want), f"{(got[i] != want).sum()} of {want.size} bytes differ"
+    if (H, W) == (oh, ow):
+        assert np.array_equal(got, img)
+
+
+@pytest.mark.gpu
+def test_prepare_images_accepts_simulator_frames(ops, dev):
+    """experiments/robot/openvla_utils.py:678-708 with 256 x 256 LIBERO simulator frames: resize -> center crop, host API and the
+    all-device path (device_pixel_values) agree bit for bit."""
+    ip, utils = load("openvla-oft_amd.image_prep"), load("openvla-oft_amd.experiments.robot.openvla_utils")
+    frames = list(_frames(np.random.default_rng(9), 2, 256, 256))
+    cfg = type("Cfg", (), {"center_crop": True})()
+    host = ip.prepare_images_for_vla(frames, cfg)
+    assert all(h.shape == (224, 224, 3) and h.dtype == np.uint8 for h in host)
+    assert np.array_equal(host[0], ip.center_crop_image(do.resize_lanczos3(frames[0], 224, 224)))
+    pv = utils.device_pixel_values(frames, cfg)
+    want = torch.cat([ip.apply_transform(h) for h in host])[None].to(BF)
+    assert torch.equal(pv.cpu(), want)
+    assert np.array_equal(ip.resize_image_for_policy(frames[1], (112, 200)), do.resize_lanczos3(frames[1], 112, 200))
