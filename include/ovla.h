@@ -326,6 +326,20 @@ int ovla_gather_rows(const ovla_gather_rows_args* a, void* stream);
  * and its backward (dpred = sign(pred-target)/count * dloss -> dx, dW, db).  The wide layers of the head run on
  * ovla_gemm_bf16 / ovla_norm_*; this is the N = ACTION_DIM tail that does not fit an MFMA tile.
  */
+/* Next-token cross entropy on selected rows (the discrete action-token objective: vla-scripts/finetune.py:357-359 `loss =
+ * output.loss`, i.e. the transformers LlamaForCausalLM loss: logits.float(), shift by one, CrossEntropyLoss(ignore_index=-100,
+ * mean) -- the caller gathers the rows whose shifted label is not ignored, so only those rows reach lm_head).
+ * logits bf16 [rows, ld] (read as fp32, as `.float()` does) ; targets int64 [rows] in [0, vocab)
+ *   loss_rows[r] = logsumexp(logits[r, :vocab]) - logits[r, target[r]]   (fp32)
+ *   argmax[r]    = lowest index of the row maximum                       (predicted_token_ids, finetune.py:358)
+ *   dlogits[r,j] = bf16((softmax(logits[r])[j] - [j == target[r]]) * grad_scale)   (optional; may alias logits)
+ * grad_scale = loss_scale / number of non-ignored tokens in the batch (the mean's 1/N and the grad-accumulation divide). */
+typedef struct {
+  const void* logits; int64_t ld; const int64_t* targets; float* loss_rows; int32_t* argmax; void* dlogits; int64_t ld_d;
+  int32_t rows, vocab; float grad_scale;
+} ovla_token_ce_args;
+int ovla_token_ce(const ovla_token_ce_args* a, void* stream);
+
 typedef struct {
   const void* x; const void* W; const void* b; void* pred;   /* bf16 */
   const void* target; float* loss_sum;                        /* optional: accumulates sum |pred-target| (or squared, mse) */

@@ -145,7 +145,72 @@ __global__ __launch_bounds__(256) void adamw_f32_kernel(float* __restrict__ p, f
   }
 }
 
+
+// One workgroup per row: max / argmax, sum of exponentials, loss, gradient.  (Rows are few -- B * (A + 1) -- and 64 KB each: the
+// three passes re-read the row from L2.)
+__global__ __launch_bounds__(256) void token_ce_kernel(const bf16_bits* __restrict__ logits, int64_t ld, const int64_t* __restrict__ targets,
+                                                       float* __restrict__ loss_rows, int* __restrict__ argmax_out, bf16_bits* dlogits, int64_t ld_d,
+                                                       int vocab, float grad_scale) {
+  __shared__ float red_f[4];
+  __shared__ int red_i[4];
+  __shared__ float bc_f[2];
+  __shared__ int bc_i;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bf16_bits* x = logits + (int64_t)row * ld;
+  int tgt = (int)targets[row];
+  tgt = tgt < 0 ? 0 : (tgt >= vocab ? vocab - 1 : tgt);   // rows with an ignored label never get here (the caller gathers); no out-of-bounds read either way
+  const float x_tgt = bf2f(x[tgt]);          // read before the barriers below: the gradient pass may overwrite the row in place
+  float m = -INFINITY; int mi = 0x7fffffff;
+  for (int j = tid; j < vocab; j += 256) {
+    const float v = bf2f(x[j]);
+    if (v > m) { m = v; mi = j; }            // j ascends per thread: the first maximum wins
+  }
+  // wave then block reduction of (max, lowest index of it)
+  for (int off = 32; off > 0; off >>= 1) {
+    const float om = __shfl_xor(m, off); const int oi = __shfl_xor(mi, off);
+    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+  }
+  if (lane == 0) { red_f[wave] = m; red_i[wave] = mi; }
+  __syncthreads();
+  if (tid == 0) {
+    float bm = red_f[0]; int bi = red_i[0];
+    for (int w = 1; w < 4; ++w) if (red_f[w] > bm || (red_f[w] == bm && red_i[w] < bi)) { bm = red_f[w]; bi = red_i[w]; }
+    bc_f[0] = bm; bc_i = bi;
+  }
+  __syncthreads();
+  m = bc_f[0];
+  float s = 0.0f;
+  for (int j = tid; j < vocab; j += 256) s += __expf(bf2f(x[j]) - m);
+  s = wave_sum(s);
+  if (lane == 0) red_f[wave] = s;
+  __syncthreads();
+  if (tid == 0) bc_f[1] = (red_f[0] + red_f[1]) + (red_f[2] + red_f[3]);
+  __syncthreads();
+  s = bc_f[1];
+  if (tid == 0) {
+    loss_rows[row] = (__logf(s) + m) - x_tgt;
+    argmax_out[row] = bc_i;
+  }
+  if (dlogits) {
+    const float inv = 1.0f / s;
+    bf16_bits* d = dlogits + (int64_t)row * ld_d;
+    for (int j = tid; j < vocab; j += 256) {
+      const float p = __expf(bf2f(x[j]) - m) * inv;
+      d[j] = f2bf((p - (j == tgt ? 1.0f : 0.0f)) * grad_scale);
+    }
+  }
+}
 }  // namespace
+
+extern "C" int ovla_token_ce(const ovla_token_ce_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->logits && a->targets && a->loss_rows && a->argmax, "ovla_token_ce: null pointer");
+  OVLA_REQUIRE(a->rows > 0 && a->vocab > 0 && a->ld >= a->vocab && (!a->dlogits || a->ld_d >= a->vocab), "ovla_token_ce: rows=%d vocab=%d ld=%lld", a->rows, a->vocab, (long long)a->ld);
+  hipLaunchKernelGGL(token_ce_kernel, dim3(a->rows), dim3(256), 0, stream, (const bf16_bits*)a->logits, a->ld, a->targets, a->loss_rows, a->argmax,
+                     (bf16_bits*)a->dlogits, a->ld_d, a->vocab, a->grad_scale);
+  OVLA_CHECK_LAUNCH("ovla_token_ce");
+  return OVLA_OK;
+}
 
 extern "C" int ovla_head_out_fwd(const ovla_head_out_fwd_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;

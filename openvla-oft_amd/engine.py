@@ -1030,6 +1030,47 @@ class VLAEngine:
         return loss_sum, pred.numel(), pred
 
 
+    def train_step_discrete(self, batch: dict, loss_scale: float = 1.0, proprio_projector=None):
+        """run_forward_pass's discrete branch (finetune.py:357-378) + backward: `loss = output.loss`, the LlamaForCausalLM
+        next-token cross entropy over the multimodal labels (logits.float(), shift by one, ignore_index -100, mean), with the
+        frozen lm_head applied ONLY to the rows whose shifted label counts (the action tokens and the stop token: A + 1 rows per
+        sample instead of all S).  Returns (loss_sum fp32[1] device, token count, predicted ids int64 [B, L - 1] on the host
+        layout of `output.logits[:, num_patches:-1].argmax(2)` with -1 where no row was evaluated)."""
+        if self.lm_head is None:
+            raise RuntimeError("the discrete objective needs language_model.lm_head.weight in the checkpoint")
+        out = self.forward(batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["labels"], proprio=batch.get("proprio"),
+                           train=True, proprio_projector=proprio_projector)
+        hidden = out["hidden"]
+        B, S, D = hidden.shape
+        P = out["P"]
+        labels = batch["labels"].to("cpu", torch.int64)
+        L = labels.shape[1]
+        # text position j (j >= 1) with labels[b, j] != -100 is predicted by the hidden state of text position j - 1, which sits at
+        # multimodal row b * S + P + (j - 1) (the BOS row is 0, the patches are rows 1..P; modeling_prismatic.py:474-496)
+        bb, jj = torch.nonzero(labels[:, 1:] != -100, as_tuple=True)
+        n_tok = int(bb.numel())
+        if n_tok == 0:
+            raise ValueError("no label in the batch is different from IGNORE_INDEX")
+        rows_idx = (bb * S + P + jj).to(torch.int32).to(self.device)
+        targets = labels[bb, jj + 1].contiguous().to(self.device)
+        n_pad = (n_tok + 7) // 8 * 8
+        x = torch.zeros((n_pad, D), dtype=BF16, device=self.device)
+        ops.gather_rows(hidden.view(B * S, D), rows_idx, D, dst=x)
+        logits = ops.gemm(x, self.lm_head)                                   # bf16 [n_pad, vocab]: lm_head under autocast
+        loss_rows, amax, dlogits = ops.token_ce(logits[:n_tok], targets, grad_scale=loss_scale / n_tok)
+        if n_pad > n_tok:
+            logits[n_tok:].zero_()
+        if getattr(self, "_lm_head_t", None) is None:
+            self._lm_head_t = ops.transpose(self.lm_head)                    # frozen: one transposed copy for the data gradient
+        dx = ops.gemm(logits, self._lm_head_t)                               # d hidden rows = dlogits @ W
+        dhidden = torch.zeros((B * S, D), dtype=BF16, device=self.device)
+        ops.gather_rows(dx, rows_idx, D, dst=dhidden, scatter_add=True)
+        self.backward_from_hidden(dhidden, out["saved"])
+        pred = torch.full((B, L - 1), -1, dtype=torch.int64)
+        pred[bb, jj] = amax.to("cpu", torch.int64)
+        return loss_rows.sum().reshape(1), n_tok, pred
+
+
 # ======================================================================================================================
 # hipGraph replay of the single-chunk inference forward (BASELINE.json configs[1])
 # ======================================================================================================================

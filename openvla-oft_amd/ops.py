@@ -507,6 +507,27 @@ def gather_rows(src, index, dim, *, dst=None, scatter_add=False, n_dst_rows=None
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+def token_ce(logits, targets, *, vocab=None, grad_scale=None, inplace_grad=True):
+    """Next-token cross entropy on gathered rows (ovla.h: ovla_token_ce): logits bf16 [rows, ld >= vocab], targets int64 [rows] ->
+    (loss_rows fp32 [rows], argmax int32 [rows], dlogits bf16 or None).  With grad_scale the gradient overwrites `logits`
+    (inplace_grad) or goes to a new tensor."""
+    _chk(logits)
+    rows = logits.shape[0]
+    vocab = logits.shape[1] if vocab is None else vocab
+    assert targets.dtype == torch.int64 and targets.numel() == rows and targets.is_contiguous() and targets.device == logits.device
+    loss_rows = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    amax = torch.empty(rows, dtype=torch.int32, device=logits.device)
+    d = None
+    if grad_scale is not None:
+        d = logits if inplace_grad else torch.empty_like(logits)
+    g = STRUCTS["ovla_token_ce_args"]()
+    g.logits, g.ld, g.targets, g.loss_rows, g.argmax = logits.data_ptr(), logits.stride(0), targets.data_ptr(), loss_rows.data_ptr(), amax.data_ptr()
+    g.dlogits, g.ld_d = _p(d), (d.stride(0) if d is not None else 0)
+    g.rows, g.vocab, g.grad_scale = rows, vocab, float(grad_scale or 0.0)
+    _lib.call("ovla_token_ce", g, _stream())
+    return loss_rows, amax, d
+
+
 def head_out_fwd(x, W, b, target=None, loss_sum=None, mse=False):
     rows, dim = x.shape
     adim = W.shape[0]

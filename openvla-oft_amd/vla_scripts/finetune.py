@@ -209,8 +209,7 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
     needs `tokenizer(text) -> ids` or tokenizer files under `cfg.vla_path`); otherwise seeded synthetic batches of the recipe's shape."""
     assert cfg.use_lora, "Only LoRA fine-tuning is supported. Please set --use_lora=True!"
     assert not (cfg.use_l1_regression and cfg.use_diffusion), "Cannot do both L1 regression and diffusion. Please pick one of them!"
-    if not (cfg.use_l1_regression or cfg.use_diffusion):
-        raise NotImplementedError("the discrete next-token objective (no continuous head) is not part of the OFT recipes built here")
+    discrete = not (cfg.use_l1_regression or cfg.use_diffusion)    # next-token cross entropy on the action tokens (finetune.py:357-378)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -228,9 +227,9 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
                                 "proprio_dim": C.PROPRIO_DIM, "norm_type": C.ACTION_PROPRIO_NORMALIZATION_TYPE.value})
     if state_dict is None:
         log(f"[finetune] no checkpoint at `{cfg.vla_path}` is loadable offline: using seeded random weights of the architecture")
-        state_dict = random_state_dict(model_config, dev, seed=0, lm_head=False, film=cfg.use_film, diffusion=cfg.use_diffusion)
+        state_dict = random_state_dict(model_config, dev, seed=0, lm_head=discrete, film=cfg.use_film, diffusion=cfg.use_diffusion)
     get, has = make_getter(state_dict, dev)
-    engine = VLAEngine(model_config, get, dev, lora=True, use_proprio=cfg.use_proprio, head="diffusion" if cfg.use_diffusion else "l1",
+    engine = VLAEngine(model_config, get, dev, lora=True, use_proprio=cfg.use_proprio, head="none" if discrete else ("diffusion" if cfg.use_diffusion else "l1"),
                        use_film=cfg.use_film, has=has)
     if cfg.use_diffusion:   # DiffusionActionHead.sample_noisy_actions (action_heads.py:167-197), host side
         from ..diffusion import DDIMScheduler, SinusoidalPositionalEncoding
@@ -276,6 +275,12 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
                 step += 1
         dataset = synthetic_stream()
     history = {"loss_value": [], "learning_rate": []}
+    if discrete:
+        from ..prismatic.training.train_utils import compute_actions_l1_loss, compute_token_accuracy
+        from ..prismatic.vla.action_tokenizer import ActionTokenizer
+
+        metric_tok = ActionTokenizer(type("Vocab", (), {"vocab_size": model_config.vocab - model_config.pad_to_multiple_of})())
+        history.update({k: [] for k in ("curr_action_accuracy", "curr_action_l1_loss", "next_actions_accuracy", "next_actions_l1_loss")})
     engine.zero_grad()
     for batch_idx, batch in enumerate(dataset):
         if not cfg.use_proprio:
@@ -287,7 +292,10 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
             tsteps = torch.randint(0, cfg.num_diffusion_steps, (gt.shape[0],), generator=noise_gen)
             diffusion = dict(noise=noise, noisy_actions=sched.add_noise(gt, noise, tsteps).to(torch.bfloat16),
                              timestep_emb=time_enc(tsteps.float()).to(torch.bfloat16))
-        loss_sum, count, _ = engine.train_step_fwd_bwd(batch, loss_scale=1.0 / cfg.grad_accumulation_steps, diffusion=diffusion)
+        if discrete:
+            loss_sum, count, pred_ids = engine.train_step_discrete(batch, loss_scale=1.0 / cfg.grad_accumulation_steps)
+        else:
+            loss_sum, count, _ = engine.train_step_fwd_bwd(batch, loss_scale=1.0 / cfg.grad_accumulation_steps, diffusion=diffusion)
         gradient_step_idx = batch_idx // cfg.grad_accumulation_steps
         log_step = gradient_step_idx if not cfg.resume else cfg.resume_step + gradient_step_idx
         if (batch_idx + 1) % cfg.grad_accumulation_steps == 0:
@@ -300,6 +308,11 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
             if log_step % cfg.wandb_log_freq == 0:
                 history["loss_value"].append(loss_sum.item() / count)
                 history["learning_rate"].append(lr)
+                if discrete:   # finetune.py:358-377
+                    gt_ids = batch["labels"][:, 1:].to("cpu")
+                    for name, m in (("curr_action", get_current_action_mask(gt_ids)), ("next_actions", get_next_actions_mask(gt_ids))):
+                        history[f"{name}_accuracy"].append(compute_token_accuracy(pred_ids, gt_ids, m).item())
+                        history[f"{name}_l1_loss"].append(compute_actions_l1_loss(metric_tok, pred_ids, gt_ids, m).item())
                 if rank == 0:
                     log(f"step {log_step}: loss {history['loss_value'][-1]:.5f} lr {lr:.2e}")
             if gradient_step_idx > 0 and log_step % cfg.save_freq == 0:

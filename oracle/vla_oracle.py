@@ -507,6 +507,19 @@ class Oracle:
             loss = self.R(self.R((gt - pred).abs()).mean())
         return loss, pred, ah
 
+    def train_forward_discrete(self, batch: dict, use_proprio=True):
+        """vla-scripts/finetune.py:357-359 (`loss = output.loss`; predicted ids = logits[:, P:-1].argmax(2)): the multimodal labels
+        are IGNORE on the patches (modeling_prismatic.py:486-496); LlamaForCausalLM shifts by one and takes the mean cross entropy
+        of the fp32-upcast logits over the labels that are not ignored.  Returns (loss, predicted ids [B, L - 1])."""
+        pv = batch["pixel_values"] if self.mode == "native" else self.R(batch["pixel_values"].float())
+        hidden, P = self.multimodal_hidden(batch["input_ids"], batch["attention_mask"], pv, batch["labels"],
+                                           batch["proprio"] if use_proprio else None)
+        logits = self.R(self.lm_logits(hidden)).float()                                 # lm_head under autocast, then .float()
+        B = hidden.shape[0]
+        mm_labels = torch.cat([batch["labels"][:, :1], torch.full((B, P), -100, dtype=batch["labels"].dtype), batch["labels"][:, 1:]], dim=1)
+        loss = F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), mm_labels[:, 1:].reshape(-1), ignore_index=-100)
+        return loss, logits[:, P:-1].argmax(dim=2)
+
     def predict_action(self, input_ids, attention_mask, pixel_values, proprio=None, unnorm_stats=None, use_film=False,
                        head: str = "l1", noise=None, num_diffusion_steps=None):
         """modeling_prismatic.py:946-1060.  head: 'l1' | 'discrete' | 'diffusion'.  Batch size 1."""

@@ -145,6 +145,23 @@ def test_finetune_loop(world, tmp_path, monkeypatch):
     assert "model.fc1.weight" in head_sd and head_sd["model.fc1.weight"].shape == (world["cfg"].llm_dim, 7 * world["cfg"].llm_dim)
 
 
+def test_finetune_discrete_objective(world, tmp_path):
+    """finetune.py:357-378: neither L1 regression nor diffusion -> next-token cross entropy on the action tokens, with the
+    reference's token-accuracy / decoded-L1 metrics; only the LoRA adapter (+ proprio projector) is trained and saved."""
+    ft = load("openvla-oft_amd.vla_scripts.finetune")
+    cfg = ft.FinetuneConfig(run_root_dir=tmp_path, dataset_name="libero_spatial_no_noops", batch_size=2, num_images_in_input=2, use_proprio=True,
+                            use_l1_regression=False, use_diffusion=False, max_steps=6, save_freq=5, wandb_log_freq=1, learning_rate=2e-3)
+    fixed = world["synth"].make_batch(2, seed=5, prompt_lens=[9, 8], image_size=56)
+    hist = ft.finetune(cfg, model_config=world["cfg"], state_dict={k: v.clone() for k, v in world["sd"].items()}, log=lambda *_: None,
+                       dataset=(fixed for _ in range(100)))
+    assert len(hist["loss_value"]) == 6 and all(np.isfinite(hist["loss_value"])) and hist["loss_value"][-1] < hist["loss_value"][0]
+    for k in ("curr_action_accuracy", "curr_action_l1_loss", "next_actions_accuracy", "next_actions_l1_loss"):
+        assert len(hist[k]) == 6 and all(np.isfinite(hist[k])), k
+    assert 0.0 <= hist["curr_action_accuracy"][-1] <= 1.0
+    names = sorted(p.name for p in list(tmp_path.glob("*--5_chkpt"))[0].iterdir())
+    assert "lora_adapter" in names and "proprio_projector--5_checkpoint.pt" in names and not any(n.startswith("action_head") for n in names)
+
+
 def test_finetune_config5_shapes(world, tmp_path):
     """BASELINE.json config 5 ingredients together: ALOHA constants (chunk 25 x action dim 14, proprio 14), 3 images,
     FiLM + diffusion head, through the fine-tune driver (reduced-size model)."""

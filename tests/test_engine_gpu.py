@@ -127,3 +127,48 @@ def test_optimizer_step_moves_toward_lower_loss(setup):
         losses.append(loss_sum.item() / count)
     print("losses", losses)
     assert losses[-1] < losses[0], losses
+
+
+def test_discrete_objective_matches_oracle(setup, dev):
+    """run_forward_pass without a continuous head (finetune.py:357-378): next-token cross entropy on the action + stop tokens
+    through the frozen lm_head.  Loss and predicted ids against the oracle, every trainable gradient against the oracle's autograd
+    (fp32) with the bf16-emulating oracle as the yardstick, as for the L1 objective above."""
+    load = importlib.import_module
+    engine_mod, weights_mod = load("openvla-oft_amd.engine"), load("openvla-oft_amd.weights")
+    ocfg, sd, batch, cfg = setup["ocfg"], setup["sd"], setup["batch"], setup["cfg"]
+    get, has = weights_mod.make_getter(sd, dev)
+    eng = engine_mod.VLAEngine(cfg, get, dev, lora=True, use_proprio=True, head="none", has=has)
+    names = set(eng.export_trainable("data"))
+    assert not any(n.startswith("action_head.") for n in names)
+    sdg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    sde = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    loss, ids32 = vo.Oracle(ocfg, sdg, mode="fp32").train_forward_discrete(batch)
+    loss.backward()
+    le, ids16 = vo.Oracle(ocfg, sde, mode="bf16").train_forward_discrete(batch)
+    le.backward()
+    eng.zero_grad()
+    loss_sum, count, pred = eng.train_step_discrete(batch)
+    counted = batch["labels"][:, 1:] != -100
+    assert count == int(counted.sum()) == 3 * 57 and pred.shape == ids16.shape and bool((pred[~counted] == -1).all())
+    got = loss_sum.item() / count
+    print(f"CE loss: hip {got:.5f}, bf16-emu {le.item():.5f}, fp32 {loss.item():.5f}")
+    assert abs(got - le.item()) < 2e-2 * max(1.0, abs(le.item())) and abs(got - loss.item()) < 3e-2 * max(1.0, abs(loss.item()))
+    agree16, emu_agree = (pred[counted] == ids16[counted]).float().mean().item(), (ids16[counted] == ids32[counted]).float().mean().item()
+    print(f"predicted ids equal to the bf16-emulating oracle's: {agree16:.3f} (that oracle vs fp32: {emu_agree:.3f})")
+    assert agree16 >= min(0.9, emu_agree - 0.05)
+    grads = eng.export_trainable("grad")
+    e_hip, e_emu, cos = {}, {}, {}
+    for n in sorted(names):
+        ref, emu, g = sdg[n].grad, sde[n].grad, grads[n].float().cpu()
+        assert g.shape == ref.shape and torch.isfinite(g).all(), n
+        if ref.norm() < 1e-7:
+            assert g.norm() < 1e-5, n
+            continue
+        e_hip[n] = ((g - ref).norm() / ref.norm()).item()
+        e_emu[n] = ((emu - ref).norm() / ref.norm()).item()
+        cos[n] = (torch.dot(g.flatten(), ref.flatten()) / (g.norm() * ref.norm())).item()
+    print(f"rel-L2 median hip {np.median(list(e_hip.values())):.4f} emu {np.median(list(e_emu.values())):.4f}; "
+          f"max hip {max(e_hip.values()):.4f} emu {max(e_emu.values()):.4f}; cosine min {min(cos.values()):.5f}")
+    assert np.median(list(e_hip.values())) <= 1.5 * np.median(list(e_emu.values())) + 5e-3
+    assert max(e_hip.values()) <= 2.0 * max(e_emu.values()) + 2e-2
+    assert min(cos.values()) > 0.98

@@ -594,3 +594,29 @@ def test_gemm_rope_epilogue(ops, dev, M, S, tile):
     ops.rope_(ref, S, 4, hd, cos, sin)
     got = ops.gemm(a, b, rope=(cos, sin, S, 4 * hd), **kw)
     assert torch.equal(got, ref), f"{(got != ref).sum().item()} of {ref.numel()} differ"
+
+
+@pytest.mark.parametrize("rows,vocab,ld", [(171, 32064, 32064), (5, 1000, 1008), (64, 257, 264)])
+def test_token_ce(ops, dev, rows, vocab, ld):
+    """ovla_token_ce == torch cross entropy on the fp32-upcast bf16 logits (per-row loss, argmax, gradient), also in place."""
+    torch.manual_seed(rows + vocab)
+    logits = torch.full((rows, ld), 7.0).to(BF)
+    logits[:, :vocab] = (torch.randn(rows, vocab) * 3).to(BF)
+    logits[0, 5] = logits[0, 9] = 30.0                                       # a tie for the maximum: the lowest index wins
+    tgt = torch.randint(0, vocab, (rows,))
+    tgt[1] = int(logits[1, :vocab].float().argmax())
+    lf = logits[:, :vocab].float().requires_grad_(True)
+    ref_rows = torch.nn.functional.cross_entropy(lf, tgt, reduction="none")
+    scale = 0.37 / rows
+    (ref_rows.sum() * scale).backward()
+    dl = logits.to(dev)
+    loss_rows, amax, d = ops.token_ce(dl, tgt.to(dev), vocab=vocab, grad_scale=scale, inplace_grad=False)
+    assert torch.allclose(loss_rows.cpu(), ref_rows.detach(), rtol=2e-5, atol=2e-5)
+    assert amax[0].item() == 5 and torch.equal(amax.cpu().long()[1:], lf.detach()[1:].argmax(1))
+    want = lf.grad.to(BF)
+    err = (d[:, :vocab].float().cpu() - want.float()).abs().max().item()
+    assert err <= 2 ** -8 * want.float().abs().max().item() + 1e-12, err
+    l2, a2, d2 = ops.token_ce(dl, tgt.to(dev), vocab=vocab, grad_scale=scale, inplace_grad=True)     # gradient overwrites the logits
+    assert d2.data_ptr() == dl.data_ptr() and torch.equal(d2[:, :vocab], d[:, :vocab]) and torch.equal(l2, loss_rows) and torch.equal(a2, amax)
+    if ld > vocab:
+        assert torch.equal(dl[:, vocab:].cpu(), logits[:, vocab:])                                 # columns past the vocabulary are untouched
