@@ -1030,7 +1030,25 @@ class VLAEngine:
         return loss_sum, pred.numel(), pred
 
 
-    def train_step_discrete(self, batch: dict, loss_scale: float = 1.0, proprio_projector=None):
+    def eval_step(self, batch: dict, diffusion=None, discrete: bool = False):
+        """run_forward_pass under torch.no_grad() (run_validation, finetune.py:678-760): the same loss as the training step,
+        no activations kept, no gradients touched.  Returns (loss_sum fp32[1] device, count, predictions)."""
+        if discrete:
+            return self.train_step_discrete(batch, backward=False)
+        cfg = self.cfg
+        kw = {}
+        if diffusion is not None:
+            kw = dict(noisy_actions=diffusion["noisy_actions"], timestep_emb=diffusion["timestep_emb"])
+        out = self.forward(batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["labels"], proprio=batch.get("proprio"),
+                           train=False, **kw)
+        B = out["hidden"].shape[0]
+        ah, _ = self.gather_action_hidden(out["hidden"], out["action_rows"])
+        tgt_src = diffusion["noise"] if diffusion is not None else batch["actions"]
+        target = tgt_src.to(self.device, BF16).reshape(B * cfg.chunk, cfg.action_dim).contiguous()
+        pred, loss_sum, _ = self.head.fwd(ah, target=target, mse=diffusion is not None, train=False)
+        return loss_sum, pred.numel(), pred
+
+    def train_step_discrete(self, batch: dict, loss_scale: float = 1.0, proprio_projector=None, backward: bool = True):
         """run_forward_pass's discrete branch (finetune.py:357-378) + backward: `loss = output.loss`, the LlamaForCausalLM
         next-token cross entropy over the multimodal labels (logits.float(), shift by one, ignore_index -100, mean), with the
         frozen lm_head applied ONLY to the rows whose shifted label counts (the action tokens and the stop token: A + 1 rows per
@@ -1039,7 +1057,7 @@ class VLAEngine:
         if self.lm_head is None:
             raise RuntimeError("the discrete objective needs language_model.lm_head.weight in the checkpoint")
         out = self.forward(batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["labels"], proprio=batch.get("proprio"),
-                           train=True, proprio_projector=proprio_projector)
+                           train=backward, proprio_projector=proprio_projector)
         hidden = out["hidden"]
         B, S, D = hidden.shape
         P = out["P"]
@@ -1057,7 +1075,11 @@ class VLAEngine:
         x = torch.zeros((n_pad, D), dtype=BF16, device=self.device)
         ops.gather_rows(hidden.view(B * S, D), rows_idx, D, dst=x)
         logits = ops.gemm(x, self.lm_head)                                   # bf16 [n_pad, vocab]: lm_head under autocast
-        loss_rows, amax, dlogits = ops.token_ce(logits[:n_tok], targets, grad_scale=loss_scale / n_tok)
+        loss_rows, amax, dlogits = ops.token_ce(logits[:n_tok], targets, grad_scale=loss_scale / n_tok if backward else None)
+        pred = torch.full((B, L - 1), -1, dtype=torch.int64)
+        pred[bb, jj] = amax.to("cpu", torch.int64)
+        if not backward:
+            return loss_rows.sum().reshape(1), n_tok, pred
         if n_pad > n_tok:
             logits[n_tok:].zero_()
         if getattr(self, "_lm_head_t", None) is None:
@@ -1066,8 +1088,6 @@ class VLAEngine:
         dhidden = torch.zeros((B * S, D), dtype=BF16, device=self.device)
         ops.gather_rows(dx, rows_idx, D, dst=dhidden, scatter_add=True)
         self.backward_from_hidden(dhidden, out["saved"])
-        pred = torch.full((B, L - 1), -1, dtype=torch.int64)
-        pred[bb, jj] = amax.to("cpu", torch.int64)
         return loss_rows.sum().reshape(1), n_tok, pred
 
 

@@ -100,8 +100,14 @@ class Episode:
         return int(self["action"].shape[0])
 
 
-def list_episodes(root: Path, dataset_name: str) -> List[Episode]:
+def list_episodes(root: Path, dataset_name: str, split: str = "train") -> List[Episode]:
+    """split "train": `<root>/<name>/episode_*`; "val": `<root>/<name>/val/episode_*` (rlds/dataset.py:238 reads the builder's
+    `train` / `val` split; a dataset without one fails there too)."""
     d = Path(root) / dataset_name
+    if split == "val":
+        if not (d / "val").is_dir():
+            raise ValueError(f"Unknown split 'val': {d} has no val/ directory of episodes")
+        d = d / "val"
     if not d.is_dir():
         raise FileNotFoundError(f"no episode store at {d} (expected {d}/episode_000000/action.npy ...; see tools/make_synthetic_episodes.py)")
     return [Episode(p) for p in sorted(d.glob("episode_*")) if (p / "action.npy").exists()]
@@ -360,23 +366,29 @@ class RLDSBatchTransform:
 
 class EpisodeDataset:
     """Drop-in for RLDSDataset (datasets.py:100-196): same constructor arguments, `dataset_statistics`, `__len__`, `__iter__` over
-    `batch_transform` outputs; infinite in train mode (the RLDS loader repeats implicitly, finetune.py:968-971)."""
+    `batch_transform` outputs; infinite in train mode (the RLDS loader repeats implicitly, finetune.py:968-971).  `train=False` reads
+    the `val/` sub-directory of the store (the builder's "val" split, rlds/dataset.py:238), one finite pass; statistics always cover
+    both splits.  `shuffle=False` / `repeat=False` give a sequential / single pass over the chosen split."""
 
     def __init__(self, data_root_dir: Path, data_mix: str, batch_transform: RLDSBatchTransform, resize_resolution: Tuple[int, int] = (224, 224),
-                 shuffle_buffer_size: int = 256_000, train: bool = True, image_aug: bool = False, *, seed: int = 0, rank: int = 0, world_size: int = 1):
+                 shuffle_buffer_size: int = 256_000, train: bool = True, image_aug: bool = False, *, seed: int = 0, rank: int = 0, world_size: int = 1,
+                 shuffle: bool = True, repeat: Optional[bool] = None):
         if data_mix not in OXE_DATASET_CONFIGS:
             raise KeyError(f"dataset `{data_mix}` is not configured (known: {sorted(OXE_DATASET_CONFIGS)})")
         self.cfg = OXE_DATASET_CONFIGS[data_mix]
         self.data_root_dir, self.data_mix, self.batch_transform = Path(data_root_dir), data_mix, batch_transform
         self.resize_resolution, self.train, self.image_aug = tuple(resize_resolution), train, image_aug
         self.seed, self.rank, self.world_size = seed, rank, world_size
+        self.shuffle, self.repeat = shuffle, (train if repeat is None else repeat)    # the validation loader is one finite pass
         if "aloha" in data_mix:
             self.load_camera_views = ("primary", "left_wrist", "right_wrist")
         else:
             self.load_camera_views = ("primary", "wrist")
-        episodes = list_episodes(self.data_root_dir, data_mix)
-        trajs = [restructure(ep, self.cfg, self.load_camera_views) for ep in episodes]
-        stats = get_dataset_statistics(trajs, (data_mix, str(self.cfg["state_obs_keys"]), self.cfg["standardize"], str(len(episodes))),
+        train_eps = list_episodes(self.data_root_dir, data_mix)
+        val_eps = list_episodes(self.data_root_dir, data_mix, "val") if (not train or (self.data_root_dir / data_mix / "val").is_dir()) else []
+        all_trajs = [restructure(ep, self.cfg, self.load_camera_views) for ep in train_eps + val_eps]      # statistics over split="all" (rlds/dataset.py:213)
+        trajs = all_trajs[: len(train_eps)] if train else all_trajs[len(train_eps):]
+        stats = get_dataset_statistics(all_trajs, (data_mix, str(self.cfg["state_obs_keys"]), self.cfg["standardize"], str(len(all_trajs))),
                                        save_dir=self.data_root_dir / data_mix)
         absolute_mask, norm_mask = action_masks(self.cfg["action_encoding"])
         stats = {**stats, "action": {**stats["action"], "mask": norm_mask}}
@@ -409,10 +421,10 @@ class EpisodeDataset:
     def __iter__(self) -> Iterator[Dict[str, Any]]:
         epoch = 0
         while True:
-            order = np.random.default_rng([self.seed, epoch]).permutation(self.dataset_length) if self.train else np.arange(self.dataset_length)
+            order = np.random.default_rng([self.seed, epoch]).permutation(self.dataset_length) if self.shuffle else np.arange(self.dataset_length)
             for j in order[self.rank::self.world_size]:
                 yield self.batch_transform(self.frame(int(self.index[j, 0]), int(self.index[j, 1])))
-            if not self.train:
+            if not self.repeat:
                 return
             epoch += 1
 

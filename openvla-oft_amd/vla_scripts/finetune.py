@@ -201,8 +201,35 @@ def load_training_checkpoint(ckpt: Path, log_step: Optional[int], engine: VLAEng
     return {"missing": missing, "optimizer": loaded_opt, "tensors": len(sd)}
 
 
+def run_validation(engine: VLAEngine, cfg: FinetuneConfig, val_batches: Iterable[dict], log_step: int, log, *, discrete: bool, make_diffusion=None,
+                   metric_fn=None) -> Dict[str, float]:
+    """finetune.py:678-760: the training loss (and, for the discrete objective, the token metrics) on the validation loader without
+    gradients, cut short after `cfg.val_time_limit` seconds, averaged over the batches seen, logged with a `val/` prefix."""
+    import time
+
+    start, rows = time.time(), []
+    for batch in val_batches:
+        if not cfg.use_proprio:
+            batch = {**batch, "proprio": None}
+        loss_sum, count, pred = engine.eval_step(batch, diffusion=make_diffusion(batch) if make_diffusion else None, discrete=discrete)
+        m = {"loss_value": loss_sum.item() / count}
+        if metric_fn is not None:
+            m.update(metric_fn(batch, pred))
+        m["loss"] = m["loss_value"]
+        rows.append(m)
+        if time.time() - start > cfg.val_time_limit:
+            break
+    if not rows:
+        return {}
+    avg = {f"val/{k}": sum(r[k] for r in rows) / len(rows) for k in rows[0]}
+    avg["val/num_batches"] = len(rows)
+    log(f"step {log_step}: " + " ".join(f"{k} {v:.5f}" for k, v in avg.items()))
+    return avg
+
+
 def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state_dict: Optional[Dict[str, torch.Tensor]] = None,
-             dataset: Optional[Iterable[dict]] = None, dataset_statistics: Optional[dict] = None, log=print, tokenizer=None) -> Dict[str, list]:
+             dataset: Optional[Iterable[dict]] = None, dataset_statistics: Optional[dict] = None, log=print, tokenizer=None,
+             val_dataset=None) -> Dict[str, list]:
     """finetune.py:763-1154.  Returns the logged metric history.  Data source, in this order: `dataset` (any iterable of collated
     batches); an episode store at `cfg.data_root_dir / cfg.dataset_name` (prismatic/vla/datasets/rlds_free.py: the reference's
     RLDSDataset + RLDSBatchTransform + collator, finetune.py:981-1016, with the frames augmented and normalised on the device --
@@ -264,6 +291,12 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
             dataset_statistics = train_dataset.dataset_statistics    # saved next to every checkpoint (finetune.py:1003-1005)
         collator = D.DeviceCollator(2048, model_config.pad_token_id, device=dev, image_aug=cfg.image_aug, seed=1000 + rank, image_size=side)
         dataset = D.batches(train_dataset, collator, cfg.batch_size)
+        if cfg.use_val_set and val_dataset is None:    # finetune.py:990-1000, 1017-1026: the store's val/ split, augmented like the training frames
+            val_ds = D.EpisodeDataset(cfg.data_root_dir, cfg.dataset_name, train_dataset.batch_transform, resize_resolution=(side, side),
+                                      shuffle_buffer_size=cfg.shuffle_buffer_size // 10, image_aug=cfg.image_aug, train=False, seed=11, rank=rank,
+                                      world_size=world)
+            val_collator = D.DeviceCollator(2048, model_config.pad_token_id, device=dev, image_aug=cfg.image_aug, seed=2000 + rank, image_size=side)
+            val_dataset = lambda: D.batches(val_ds, val_collator, cfg.batch_size)  # noqa: E731
         log(f"[finetune] episode store {cfg.data_root_dir / cfg.dataset_name}: {len(train_dataset)} frames, image_aug={cfg.image_aug}")
     if dataset is None:
         def synthetic_stream():
@@ -274,24 +307,34 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
                                            image_size=model_config.dino.image_size)
                 step += 1
         dataset = synthetic_stream()
-    history = {"loss_value": [], "learning_rate": []}
+    if cfg.use_val_set and val_dataset is None:
+        raise ValueError("use_val_set=True needs a validation source: an episode store with a val/ split, or `val_dataset` (a callable returning an iterable of batches)")
+    history = {"loss_value": [], "learning_rate": [], "val": []}
     if discrete:
         from ..prismatic.training.train_utils import compute_actions_l1_loss, compute_token_accuracy
         from ..prismatic.vla.action_tokenizer import ActionTokenizer
 
         metric_tok = ActionTokenizer(type("Vocab", (), {"vocab_size": model_config.vocab - model_config.pad_to_multiple_of})())
         history.update({k: [] for k in ("curr_action_accuracy", "curr_action_l1_loss", "next_actions_accuracy", "next_actions_l1_loss")})
+    def make_diffusion(batch):   # DiffusionActionHead.sample_noisy_actions (action_heads.py:167-197)
+        gt = batch["actions"].to("cpu", torch.float32)
+        noise = torch.randn(gt.shape, generator=noise_gen).to(torch.bfloat16).float()
+        tsteps = torch.randint(0, cfg.num_diffusion_steps, (gt.shape[0],), generator=noise_gen)
+        return dict(noise=noise, noisy_actions=sched.add_noise(gt, noise, tsteps).to(torch.bfloat16), timestep_emb=time_enc(tsteps.float()).to(torch.bfloat16))
+
+    def token_metrics(batch, pred_ids):   # finetune.py:358-377
+        gt_ids = batch["labels"][:, 1:].to("cpu")
+        out = {}
+        for name, m in (("curr_action", get_current_action_mask(gt_ids)), ("next_actions", get_next_actions_mask(gt_ids))):
+            out[f"{name}_accuracy"] = compute_token_accuracy(pred_ids, gt_ids, m).item()
+            out[f"{name}_l1_loss"] = compute_actions_l1_loss(metric_tok, pred_ids, gt_ids, m).item()
+        return out
+
     engine.zero_grad()
     for batch_idx, batch in enumerate(dataset):
         if not cfg.use_proprio:
             batch = {**batch, "proprio": None}
-        diffusion = None
-        if cfg.use_diffusion:
-            gt = batch["actions"].to("cpu", torch.float32)
-            noise = torch.randn(gt.shape, generator=noise_gen).to(torch.bfloat16).float()
-            tsteps = torch.randint(0, cfg.num_diffusion_steps, (gt.shape[0],), generator=noise_gen)
-            diffusion = dict(noise=noise, noisy_actions=sched.add_noise(gt, noise, tsteps).to(torch.bfloat16),
-                             timestep_emb=time_enc(tsteps.float()).to(torch.bfloat16))
+        diffusion = make_diffusion(batch) if cfg.use_diffusion else None
         if discrete:
             loss_sum, count, pred_ids = engine.train_step_discrete(batch, loss_scale=1.0 / cfg.grad_accumulation_steps)
         else:
@@ -308,13 +351,15 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
             if log_step % cfg.wandb_log_freq == 0:
                 history["loss_value"].append(loss_sum.item() / count)
                 history["learning_rate"].append(lr)
-                if discrete:   # finetune.py:358-377
-                    gt_ids = batch["labels"][:, 1:].to("cpu")
-                    for name, m in (("curr_action", get_current_action_mask(gt_ids)), ("next_actions", get_next_actions_mask(gt_ids))):
-                        history[f"{name}_accuracy"].append(compute_token_accuracy(pred_ids, gt_ids, m).item())
-                        history[f"{name}_l1_loss"].append(compute_actions_l1_loss(metric_tok, pred_ids, gt_ids, m).item())
+                if discrete:
+                    for k, v in token_metrics(batch, pred_ids).items():
+                        history[k].append(v)
                 if rank == 0:
                     log(f"step {log_step}: loss {history['loss_value'][-1]:.5f} lr {lr:.2e}")
+            if cfg.use_val_set and log_step > 0 and log_step % cfg.val_freq == 0:   # finetune.py:1128-1144
+                history["val"].append((log_step, run_validation(engine, cfg, val_dataset(), log_step, log if rank == 0 else (lambda *_: None), discrete=discrete,
+                                                                make_diffusion=make_diffusion if cfg.use_diffusion else None,
+                                                                metric_fn=token_metrics if discrete else None)))
             if gradient_step_idx > 0 and log_step % cfg.save_freq == 0:
                 save_training_checkpoint(run_dir, log_step, engine, dataset_statistics, rank, cfg.save_latest_checkpoint_only)
                 if world > 1:

@@ -119,7 +119,7 @@ def test_episode_dataset_frames_and_rank_partition(tmp_path):
     synth.write_synthetic_episodes(tmp_path, n_episodes=4, unlabeled_every=4, min_len=20, max_len=30, image_size=32)
     tok = Tok()
     bt = R.RLDSBatchTransform(AT.ActionTokenizer(tok), tok, use_wrist_image=True, use_proprio=True)
-    ds = D.RLDSDataset(tmp_path, "libero_spatial_no_noops", bt, resize_resolution=(32, 32), train=False)
+    ds = D.RLDSDataset(tmp_path, "libero_spatial_no_noops", bt, resize_resolution=(32, 32), shuffle=False, repeat=False)
     eps = R.list_episodes(tmp_path, "libero_spatial_no_noops")
     assert len(ds) == sum(len(e) - 7 for e in eps[:3])                      # the unlabeled episode is skipped, T - 7 frames each
     stats = ds.dataset_statistics["libero_spatial_no_noops"]
@@ -140,6 +140,14 @@ def test_episode_dataset_frames_and_rank_partition(tmp_path):
     assert len(set(seen[0]) & set(seen[1])) == 0 and len(set(seen[0]) | set(seen[1])) == 2 * (len(ds) // 2)
     with pytest.raises(KeyError):
         D.RLDSDataset(tmp_path, "not_a_dataset", bt)
+    # the validation split is the store's val/ directory (the builder's "val" split); statistics cover both
+    with pytest.raises(ValueError, match="Unknown split 'val'"):
+        D.RLDSDataset(tmp_path, "libero_spatial_no_noops", bt, resize_resolution=(32, 32), train=False)
+    synth.write_synthetic_episodes(tmp_path / "v", n_episodes=1, seed=9, min_len=20, max_len=20, image_size=32)
+    (tmp_path / "v" / "libero_spatial_no_noops").rename(tmp_path / "libero_spatial_no_noops" / "val")
+    val = D.RLDSDataset(tmp_path, "libero_spatial_no_noops", bt, resize_resolution=(32, 32), train=False)
+    assert len(val) == 13 and len(list(val)) == 13 and val.dataset_statistics["libero_spatial_no_noops"]["num_trajectories"] == 5
+    assert len(D.RLDSDataset(tmp_path, "libero_spatial_no_noops", bt, resize_resolution=(32, 32))) == len(ds)
 
 
 def test_augment_parameter_distributions():
@@ -263,7 +271,7 @@ def test_device_collator_batch_layout(tmp_path, ops, dev):
     synth.write_synthetic_episodes(tmp_path, n_episodes=2, min_len=12, max_len=14)
     tok = Tok()
     bt = R.RLDSBatchTransform(AT.ActionTokenizer(tok), tok, use_wrist_image=True, use_proprio=True)
-    ds = D.RLDSDataset(tmp_path, "libero_spatial_no_noops", bt, train=False)
+    ds = D.RLDSDataset(tmp_path, "libero_spatial_no_noops", bt, shuffle=False, repeat=False)
     inst = [s for _, s in zip(range(3), ds)]
     inst[1]["input_ids"], inst[1]["labels"] = inst[1]["input_ids"][2:], inst[1]["labels"][2:]          # a shorter row -> right padding
     batch = R.DeviceCollator(2048, 32000, device=dev, image_aug=True, seed=11)(inst)
@@ -296,15 +304,20 @@ def test_finetune_reads_an_episode_store(tmp_path, dev):
     mc = config_mod.VLAConfig.from_any(ocfg)
     side = mc.dino.image_size
     synth.write_synthetic_episodes(tmp_path / "data", n_episodes=3, min_len=12, max_len=16, image_size=side)
+    synth.write_synthetic_episodes(tmp_path / "v", n_episodes=1, seed=9, min_len=12, max_len=12, image_size=side)
+    (tmp_path / "v" / "libero_spatial_no_noops").rename(tmp_path / "data" / "libero_spatial_no_noops" / "val")
     cfg = ft.FinetuneConfig(run_root_dir=tmp_path / "runs", data_root_dir=tmp_path / "data", dataset_name="libero_spatial_no_noops", batch_size=2,
-                            num_images_in_input=2, use_proprio=True, max_steps=3, save_freq=2, wandb_log_freq=1, image_aug=True)
+                            num_images_in_input=2, use_proprio=True, max_steps=3, save_freq=2, wandb_log_freq=1, image_aug=True, use_val_set=True, val_freq=2)
     lines = []
     hist = ft.finetune(cfg, model_config=mc, state_dict=sd, log=lines.append, tokenizer=Tok())
     assert len(hist["loss_value"]) == 3 and all(np.isfinite(hist["loss_value"]))
+    # run_validation (finetune.py:678-760) at step 2: one pass over the val/ split (5 frames -> 3 batches), loss without gradients
+    assert [s for s, _ in hist["val"]] == [2] and hist["val"][0][1]["val/num_batches"] == 3 and np.isfinite(hist["val"][0][1]["val/loss"])
+    assert any("val/loss_value" in str(l) for l in lines)
     assert any("episode store" in str(l) for l in lines)
     ck = list((tmp_path / "runs").glob("*--2_chkpt"))[0]
     stats = json.loads((ck / "dataset_statistics.json").read_text())
-    assert stats["libero_spatial_no_noops"]["action"]["mask"] == [True] * 6 + [False] and stats["libero_spatial_no_noops"]["num_trajectories"] == 3
+    assert stats["libero_spatial_no_noops"]["action"]["mask"] == [True] * 6 + [False] and stats["libero_spatial_no_noops"]["num_trajectories"] == 4
 
 
 @pytest.mark.gpu
