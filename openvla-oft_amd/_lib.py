@@ -17,6 +17,8 @@ LIB_PATH = _PKG_DIR / "libovla_hip.so"
 
 _CTYPE = {
     "void*": ctypes.c_void_p,
+    "void**": ctypes.POINTER(ctypes.c_void_p),
+    "void": None,
     "float*": ctypes.c_void_p,
     "int32_t*": ctypes.c_void_p,
     "int64_t*": ctypes.c_void_p,
