@@ -194,56 +194,11 @@ __global__ __launch_bounds__(256) void norm_fwd_wave_kernel(const bf16_bits* __r
   }
 }
 
-template <int CPL>
-__global__ __launch_bounds__(256) void norm_bwd_wave_kernel(const bf16_bits* __restrict__ x, const bf16_bits* __restrict__ dy,
-                                                            const bf16_bits* __restrict__ w, const float* __restrict__ mean_in,
-                                                            const float* __restrict__ rstd_in, bf16_bits* __restrict__ dx, int rows,
-                                                            int dim, int is_rms, int dx_accum) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const bf16_bits* xr = x + row * dim;
-  const bf16_bits* dyr = dy + row * dim;
-  bf16_bits* dxr = dx + row * dim;
-  const float mean = is_rms ? 0.f : mean_in[row];
-  const float rstd = rstd_in[row];
-  const int nchunk = dim >> 3;
-  float xh[CPL][8], gw[CPL][8];
-  float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-  for (int i = 0; i < CPL; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunk) {
-      float g[8], wf[8];
-      load8(xr + c * 8, xh[i]);
-      load8(dyr + c * 8, g);
-      load8(w + c * 8, wf);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        gw[i][j] = g[j] * wf[j];
-        xh[i][j] = (xh[i][j] - mean) * rstd;
-        s1 += gw[i][j];
-        s2 += gw[i][j] * xh[i][j];
-      }
-    }
-  }
-  const float m1 = is_rms ? 0.f : wave_sum(s1) / (float)dim;
-  const float m2 = wave_sum(s2) / (float)dim;
-#pragma unroll
-  for (int i = 0; i < CPL; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunk) {
-      float o[8];
-      if (dx_accum) load8(dxr + c * 8, o);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = rstd * (gw[i][j] - m1 - xh[i][j] * m2);
-        o[j] = dx_accum ? o[j] + v : v;
-      }
-      store8(dxr + c * 8, o);
-    }
-  }
-}
+// (A wave-per-row BACKWARD kernel like norm_fwd_wave_kernel existed; it was bit-exact on one stream but, with the second vision
+// tower's kernels running beside it on another stream, a handful of waves per launch computed their row with a slightly different
+// row mean of dy * w (1-2 bf16 ulp in the outputs; found with tools/determinism_check.py, not explained: neither the cross-lane
+// reduction, ds_bpermute or DPP, nor the load waits were at fault).  The workgroup-per-row norm_bwd_kernel below is stable under the same
+// concurrency and the step time is the same, so the backward uses it for every width.)
 
 // ---------------------------------------------------------------------------------------------------------------
 // RoPE tables and in-place rotation.  HF convention: cos/sin are fp32, cast to bf16; q' = bf16(bf16(q*c) + bf16(rot(q)*s)).
@@ -1009,17 +964,9 @@ extern "C" int ovla_norm_bwd(const ovla_norm_bwd_args* a, void* stream_) {
   OVLA_REQUIRE(a->is_rms || a->mean, "ovla_norm_bwd: LayerNorm needs mean");
   OVLA_REQUIRE(a->rows > 0 && a->dim > 0 && (a->dim % 8) == 0, "ovla_norm_bwd: rows=%d dim=%d", a->rows, a->dim);
   OVLA_REQUIRE(aligned16(a->x) && aligned16(a->dy) && aligned16(a->dx) && aligned16(a->weight), "ovla_norm_bwd: 16-byte alignment");
-#define OVLA_NORM_BWD_WAVE(CPL)                                                                                                                 \
-  hipLaunchKernelGGL(norm_bwd_wave_kernel<CPL>, dim3(cdiv(a->rows, 4)), dim3(256), 0, stream, (const bf16_bits*)a->x, (const bf16_bits*)a->dy, \
-                     (const bf16_bits*)a->weight, a->mean, a->rstd, (bf16_bits*)a->dx, a->rows, a->dim, a->is_rms, a->dx_accum)
-  const bool no_wgrad = !a->dweight && !a->dbias;   // frozen norms (everything except the action head): the row-in-registers kernel
-  if (no_wgrad && a->dim <= 1024) OVLA_NORM_BWD_WAVE(2);
-  else if (no_wgrad && a->dim <= 1536) OVLA_NORM_BWD_WAVE(3);
-  else
-    hipLaunchKernelGGL(norm_bwd_kernel, dim3(a->rows), dim3(256), 0, stream, (const bf16_bits*)a->x, (const bf16_bits*)a->dy,
-                       (const bf16_bits*)a->weight, a->mean, a->rstd, (bf16_bits*)a->dx, a->dweight, a->dbias, a->dim, a->is_rms,
-                       a->dx_accum);
-#undef OVLA_NORM_BWD_WAVE
+  hipLaunchKernelGGL(norm_bwd_kernel, dim3(a->rows), dim3(256), 0, stream, (const bf16_bits*)a->x, (const bf16_bits*)a->dy,
+                     (const bf16_bits*)a->weight, a->mean, a->rstd, (bf16_bits*)a->dx, a->dweight, a->dbias, a->dim, a->is_rms,
+                     a->dx_accum);
   OVLA_CHECK_LAUNCH("ovla_norm_bwd");
   return OVLA_OK;
 }
