@@ -370,7 +370,8 @@ class VitTower:
         saved, B = saved_all
         T = vc.n_patches + vc.n_prefix
         H, hd = vc.heads, vc.head_dim
-        for blk, sv in zip(reversed(self.blocks), reversed(saved)):
+        for bi, (blk, sv) in enumerate(zip(reversed(self.blocks), reversed(saved))):
+            first_block = bi == len(saved) - 1      # block 0: nothing upstream is trainable (patch / position embeddings are frozen)
             x, mean1, rstd1, s_qkv, qkv, o, lse, s_proj, x2, mean2, rstd2, s_fc1, z, s_fc2, fsv = sv
             # x3 = x2 + ls2 * fc2(act(fc1(ln2(x2))))
             d = ops.colscale(dx, blk["ls2"]) if blk["ls2"] is not None else dx
@@ -395,8 +396,9 @@ class VitTower:
             D = vc.dim
             ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, do, lse, B, T, H, hd, dq=dqkv[:, :D], dk=dqkv[:, D:2 * D],
                          dv=dqkv[:, 2 * D:])
-            dh1 = blk["qkv"].bwd(dqkv, s_qkv)
-            ops.norm_bwd(x, dh1, blk["ln1_w"], mean1, rstd1, rms=False, dx=dx, dx_accum=True)        # dx now = d x
+            dh1 = blk["qkv"].bwd(dqkv, s_qkv, need_dx=not first_block)   # block 0 still needs its LoRA gradients, not d x
+            if not first_block:
+                ops.norm_bwd(x, dh1, blk["ln1_w"], mean1, rstd1, rms=False, dx=dx, dx_accum=True)    # dx now = d x
         return None  # patch embedding / position embedding are frozen and the pixels need no gradient
 
 
