@@ -368,8 +368,9 @@ def main():
         b1["proprio"] = b1["proprio"].to(dev, torch.bfloat16).reshape(1, -1)
 
         def infer_once():
-            out = eng.forward(b1["input_ids"], b1["attention_mask"], b1["pixel_values"], b1["labels"], proprio=b1["proprio"], train=False)
-            ah, _ = eng.gather_action_hidden(out["hidden"], out["action_rows"])
+            out = eng.forward(b1["input_ids"], b1["attention_mask"], b1["pixel_values"], b1["labels"], proprio=b1["proprio"], train=False,
+                              sel="actions")     # as predict_action does: the last layer's projections only on the 56 action rows
+            ah, _ = eng.action_hidden(out)
             return eng.head.fwd(ah)[0]
 
         def time_it(fn, n=20):

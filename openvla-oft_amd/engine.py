@@ -438,14 +438,21 @@ class LlamaStack:
             self.cos, self.sin = ops.rope_table(n, self.hd, self.cfg.rope_theta, device)
         return self.cos, self.sin
 
-    def fwd(self, x, B: int, S: int, kv_len, train: bool):
-        """x bf16 [B*S, D] (inputs_embeds) -> (hidden_states[-1] [B*S, D] (post final norm), saved)."""
+    def fwd(self, x, B: int, S: int, kv_len, train: bool, sel=None):
+        """x bf16 [B*S, D] (inputs_embeds) -> (hidden_states[-1] [B*S, D] (post final norm), saved).
+        `sel` (int32 [n], flattened (b, s) rows, n % 8 == 0): only these rows of hidden_states[-1] are wanted (the rows that predict
+        the action tokens: everything else of the last layer's output is discarded by run_forward_pass / predict_action).  The last
+        layer then runs its attention-output projection, MLP and the final norm on those n rows only (K / V still come from every
+        row) and the result is [n, D] in `sel` order -- the same numbers, 9 % of the rows for three of its four GEMMs."""
         cfg = self.cfg
         D, H, hd, F = cfg.llm_dim, cfg.llm_heads, self.hd, cfg.llm_ff
         cos, sin = self._tables(S, x.device)
         causal = cfg.mask_mode == "causal"
         saved = []
-        for l in self.layers:
+        if sel is not None and (sel.numel() % 8 != 0 or sel.numel() == 0):
+            raise ValueError("LlamaStack.fwd: the number of selected rows must be a positive multiple of 8")
+        for li, l in enumerate(self.layers):
+            last_sel = sel is not None and li == len(self.layers) - 1
             h1, _, r1 = ops.norm_fwd(x, l["n1"], eps=cfg.rms_eps, rms=True, save_stats=train)
             if _FUSE_ROPE_FWD and hd == 128:    # RoPE on the q | k heads in the projection's epilogue (ovla_gemm_args.rope_*)
                 qkv, s_qkv = l["qkv"].fwd(h1, rope=(cos, sin, S, 2 * D))
@@ -453,7 +460,10 @@ class LlamaStack:
                 qkv, s_qkv = l["qkv"].fwd(h1)
                 ops.rope_(qkv, S, 2 * H, hd, cos, sin)
             o, lse = ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, S, H, hd, kv_len=kv_len, causal=causal)
-            x2, s_o = l["o"].fwd(o, residual=x)
+            if last_sel:
+                x2, s_o = l["o"].fwd(ops.gather_rows(o, sel, D), residual=ops.gather_rows(x, sel, D))
+            else:
+                x2, s_o = l["o"].fwd(o, residual=x)
             h2, _, r2 = ops.norm_fwd(x2, l["n2"], eps=cfg.rms_eps, rms=True, save_stats=train)
             gu, s_gu = l["gu"].fwd(h2)
             hm = ops.swiglu_fwd(gu)
@@ -462,12 +472,13 @@ class LlamaStack:
                 saved.append((x, r1, s_qkv, qkv, o, lse, s_o, x2, r2, s_gu, gu, s_d))
             x = x3
         out, _, rf = ops.norm_fwd(x, self.norm_w, eps=cfg.rms_eps, rms=True, save_stats=train)
-        return out, (saved, x, rf, B, S, kv_len)
+        return out, (saved, x, rf, B, S, kv_len, sel)
 
     def bwd(self, dout, saved_all):
-        """dout [B*S, D] gradient of hidden_states[-1] -> gradient of inputs_embeds (in a fresh buffer)."""
+        """dout [B*S, D] gradient of hidden_states[-1] ([n, D] for the selected rows if the forward ran with `sel`) -> gradient of
+        inputs_embeds (in a fresh buffer)."""
         cfg = self.cfg
-        saved, x_last, rf, B, S, kv_len = saved_all
+        saved, x_last, rf, B, S, kv_len, sel = saved_all
         D, H, hd, F = cfg.llm_dim, cfg.llm_heads, self.hd, cfg.llm_ff
         causal = cfg.mask_mode == "causal"
         dx = ops.norm_bwd(x_last, dout, self.norm_w, None, rf, rms=True)
@@ -480,6 +491,12 @@ class LlamaStack:
             dh2 = l["gu"].bwd(dgu, s_gu)
             ops.norm_bwd(x2, dh2, l["n2"], None, r2, rms=True, dx=dx, dx_accum=True)                   # dx = d x2
             do = l["o"].bwd(dx, s_o)
+            if sel is not None and li == 0:   # last layer on the selected rows: back to all rows (zero gradient everywhere else)
+                do_full = torch.zeros((B * S, D), dtype=BF16, device=dx.device)
+                dx_full = torch.zeros((B * S, D), dtype=BF16, device=dx.device)
+                ops.gather_rows(do, sel, D, dst=do_full, scatter_add=True)
+                ops.gather_rows(dx, sel, D, dst=dx_full, scatter_add=True)                             # the residual x -> x2 at those rows
+                do, dx = do_full, dx_full
             dqkv = torch.empty_like(qkv)
             # dq / dk leave the attention backward already rotated back (inverse RoPE in its epilogues: no separate pass)
             ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, do, lse, B, S, H, hd, kv_len=kv_len, causal=causal,
@@ -889,11 +906,12 @@ class VLAEngine:
         return avg
 
     def forward(self, input_ids, attention_mask, pixel_values, labels, proprio=None, noisy_actions=None, timestep_emb=None, train=False,
-                proprio_projector=None, noisy_action_projector=None, cached_patches=None):
+                proprio_projector=None, noisy_action_projector=None, cached_patches=None, sel=None):
         """Multimodal forward (modeling_prismatic.py:571-643 without the discarded lm_head/CE in L1/diffusion mode).
         Returns dict(hidden [B,S,D], P, action_rows [B,A], patches, saved).  `cached_patches` (the `patches` of a previous
         call) skips the vision towers / projector / proprio projector: the DDIM sampler reuses them across its steps
-        (modeling_prismatic.py:810)."""
+        (modeling_prismatic.py:810).  `sel="actions"` (or an int32 tensor of flattened rows): only those rows of the last hidden state
+        are computed (LlamaStack.fwd) and returned as `action_hidden` [n, D]; `hidden` is then None."""
         dev = self.device
         B, L = input_ids.shape
         ids = input_ids.to(dev, torch.int64).contiguous()
@@ -904,7 +922,7 @@ class VLAEngine:
             film_avg = self.language_average(ids, labels.to("cpu"))
         return self.forward_dev(ids, lab, lens.to(torch.int32).to(dev), pixel_values, proprio=proprio, noisy_actions=noisy_actions,
                                 timestep_emb=timestep_emb, train=train, proprio_projector=proprio_projector,
-                                noisy_action_projector=noisy_action_projector, cached_patches=cached_patches, film_avg=film_avg)
+                                noisy_action_projector=noisy_action_projector, cached_patches=cached_patches, film_avg=film_avg, sel=sel)
 
     @staticmethod
     def check_right_padding(attention_mask) -> torch.Tensor:
@@ -917,7 +935,7 @@ class VLAEngine:
         return lens
 
     def forward_dev(self, ids, lab, text_lens, pixel_values, proprio=None, noisy_actions=None, timestep_emb=None, train=False,
-                    proprio_projector=None, noisy_action_projector=None, cached_patches=None, film_avg=None):
+                    proprio_projector=None, noisy_action_projector=None, cached_patches=None, film_avg=None, sel=None):
         """Device-only part of forward(): ids / lab int64 [B, L] and text_lens int32 [B] already on the device; launches
         kernels and allocates, never synchronises or reads host memory -- the part a hipGraph can capture (ChunkGraph)."""
         cfg = self.cfg
@@ -956,9 +974,24 @@ class VLAEngine:
         mm, action_rows = ops.assemble_multimodal(ids, lab, self.embed, allp.contiguous(), A=A, noisy=noisy_feats, action_dim=cfg.action_dim)
         S = P + L
         kv_len = (text_lens + P).to(torch.int32)
-        hidden, lsaved = self.llm.fwd(mm.view(B * S, cfg.llm_dim), B, S, kv_len, train)
+        sel_rows = None
+        if sel is not None and os.environ.get("OVLA_LAST_LAYER_SEL", "1") != "0":    # A/B switch
+            sel_rows = action_rows.reshape(-1) if isinstance(sel, str) else sel
+            if sel_rows.numel() % 8 != 0:
+                sel_rows = None          # (e.g. ALOHA discrete: 4 x 351 rows) -> the full last layer
+        hidden, lsaved = self.llm.fwd(mm.view(B * S, cfg.llm_dim), B, S, kv_len, train, sel=sel_rows)
         saved = (vsaved, psaved, nsaved, lsaved, B, S, P, n_vis, proprio_projector, noisy_action_projector, action_rows) if train else None
-        return dict(hidden=hidden.view(B, S, cfg.llm_dim), P=P, action_rows=action_rows, patches=(base, n_vis), saved=saved)
+        if sel_rows is not None:
+            return dict(hidden=None, action_hidden=hidden, sel_rows=sel_rows, P=P, S=S, action_rows=action_rows, patches=(base, n_vis), saved=saved)
+        return dict(hidden=hidden.view(B, S, cfg.llm_dim), action_hidden=None, sel_rows=None, P=P, S=S, action_rows=action_rows, patches=(base, n_vis),
+                    saved=saved)
+
+    def action_hidden(self, out):
+        """(hidden rows that predict the action slots [B*A, D], their flattened row indices) of a forward() result, whether the last
+        layer ran on the selected rows only (`sel="actions"`) or on all of them."""
+        if out.get("action_hidden") is not None:
+            return out["action_hidden"], out["sel_rows"]
+        return self.gather_action_hidden(out["hidden"], out["action_rows"])
 
     def gather_action_hidden(self, hidden, action_rows):
         """Rows of hidden that predict the action slots: the hidden state at token i-1 predicts token i
@@ -969,7 +1002,8 @@ class VLAEngine:
         return ops.gather_rows(hidden.view(B * S, D), idx, D), idx
 
     def backward_from_hidden(self, dhidden, saved):
-        """dhidden bf16 [B*S, D] (gradient of hidden_states[-1]) -> accumulates every VLM / projector gradient."""
+        """dhidden bf16 [B*S, D] (gradient of hidden_states[-1]; [n, D] for the selected rows when the forward ran with `sel`) ->
+        accumulates every VLM / projector gradient."""
         vsaved, psaved, nsaved, lsaved, B, S, P, n_vis, proprio_projector, noisy_action_projector, action_rows = saved
         D = self.cfg.llm_dim
         dmm_flat = self.llm.bwd(dhidden, lsaved)
@@ -1014,10 +1048,9 @@ class VLAEngine:
         if diffusion is not None:
             kw = dict(noisy_actions=diffusion["noisy_actions"], timestep_emb=diffusion["timestep_emb"], noisy_action_projector=noisy_action_projector)
         out = self.forward(batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["labels"], proprio=batch.get("proprio"),
-                           train=True, proprio_projector=proprio_projector, **kw)
-        hidden = out["hidden"]
-        B, S, D = hidden.shape
-        ah, idx = self.gather_action_hidden(hidden, out["action_rows"])
+                           train=True, proprio_projector=proprio_projector, sel="actions", **kw)
+        B, S, D = batch["input_ids"].shape[0], out["S"], cfg.llm_dim
+        ah, idx = self.action_hidden(out)
         tgt_src = diffusion["noise"] if diffusion is not None else batch["actions"]
         target = tgt_src.to(self.device, BF16).reshape(B * cfg.chunk, cfg.action_dim).contiguous()
         pred, loss_sum, hsaved = head.fwd(ah, target=target, mse=diffusion is not None, train=True)
@@ -1026,9 +1059,12 @@ class VLAEngine:
         if getattr(self, "_overlap", False) and hasattr(head, "store"):
             for dt, g in head.store.flat_grad.items():
                 self.reducer.notify(head.store, dt, g.numel())
-        dhidden = torch.zeros((B * S, D), dtype=BF16, device=self.device)
-        ops.gather_rows(dah, idx, D, dst=dhidden, scatter_add=True)
-        self.backward_from_hidden(dhidden, out["saved"])
+        if out["sel_rows"] is not None:
+            self.backward_from_hidden(dah, out["saved"])            # the last layer ran on exactly these rows
+        else:
+            dhidden = torch.zeros((B * S, D), dtype=BF16, device=self.device)
+            ops.gather_rows(dah, idx, D, dst=dhidden, scatter_add=True)
+            self.backward_from_hidden(dhidden, out["saved"])
         return loss_sum, pred.numel(), pred
 
 
@@ -1042,9 +1078,9 @@ class VLAEngine:
         if diffusion is not None:
             kw = dict(noisy_actions=diffusion["noisy_actions"], timestep_emb=diffusion["timestep_emb"])
         out = self.forward(batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["labels"], proprio=batch.get("proprio"),
-                           train=False, **kw)
-        B = out["hidden"].shape[0]
-        ah, _ = self.gather_action_hidden(out["hidden"], out["action_rows"])
+                           train=False, sel="actions", **kw)
+        B = batch["input_ids"].shape[0]
+        ah, _ = self.action_hidden(out)
         tgt_src = diffusion["noise"] if diffusion is not None else batch["actions"]
         target = tgt_src.to(self.device, BF16).reshape(B * cfg.chunk, cfg.action_dim).contiguous()
         pred, loss_sum, _ = self.head.fwd(ah, target=target, mse=diffusion is not None, train=False)
@@ -1058,13 +1094,12 @@ class VLAEngine:
         layout of `output.logits[:, num_patches:-1].argmax(2)` with -1 where no row was evaluated)."""
         if self.lm_head is None:
             raise RuntimeError("the discrete objective needs language_model.lm_head.weight in the checkpoint")
-        out = self.forward(batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["labels"], proprio=batch.get("proprio"),
-                           train=backward, proprio_projector=proprio_projector)
-        hidden = out["hidden"]
-        B, S, D = hidden.shape
-        P = out["P"]
         labels = batch["labels"].to("cpu", torch.int64)
-        L = labels.shape[1]
+        B, L = labels.shape
+        D = self.cfg.llm_dim
+        use_pp = batch.get("proprio") is not None and (proprio_projector is not None or self.proprio is not None)
+        P = self.num_patches_total(batch["pixel_values"].shape[1] // 6, use_pp)
+        S = P + L
         # text position j (j >= 1) with labels[b, j] != -100 is predicted by the hidden state of text position j - 1, which sits at
         # multimodal row b * S + P + (j - 1) (the BOS row is 0, the patches are rows 1..P; modeling_prismatic.py:474-496)
         bb, jj = torch.nonzero(labels[:, 1:] != -100, as_tuple=True)
@@ -1073,9 +1108,15 @@ class VLAEngine:
             raise ValueError("no label in the batch is different from IGNORE_INDEX")
         rows_idx = (bb * S + P + jj).to(torch.int32).to(self.device)
         targets = labels[bb, jj + 1].contiguous().to(self.device)
+        out = self.forward(batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["labels"], proprio=batch.get("proprio"),
+                           train=backward, proprio_projector=proprio_projector, sel=rows_idx)     # last layer on the counted rows only
+        assert out["P"] == P and out["S"] == S
         n_pad = (n_tok + 7) // 8 * 8
-        x = torch.zeros((n_pad, D), dtype=BF16, device=self.device)
-        ops.gather_rows(hidden.view(B * S, D), rows_idx, D, dst=x)
+        if out["sel_rows"] is not None:
+            x = out["action_hidden"]                       # n_tok % 8 == 0: already the gathered rows
+        else:
+            x = torch.zeros((n_pad, D), dtype=BF16, device=self.device)
+            ops.gather_rows(out["hidden"].view(B * S, D), rows_idx, D, dst=x)
         logits = ops.gemm(x, self.lm_head)                                   # bf16 [n_pad, vocab]: lm_head under autocast
         loss_rows, amax, dlogits = ops.token_ce(logits[:n_tok], targets, grad_scale=loss_scale / n_tok if backward else None)
         pred = torch.full((B, L - 1), -1, dtype=torch.int64)
@@ -1087,9 +1128,12 @@ class VLAEngine:
         if getattr(self, "_lm_head_t", None) is None:
             self._lm_head_t = ops.transpose(self.lm_head)                    # frozen: one transposed copy for the data gradient
         dx = ops.gemm(logits, self._lm_head_t)                               # d hidden rows = dlogits @ W
-        dhidden = torch.zeros((B * S, D), dtype=BF16, device=self.device)
-        ops.gather_rows(dx, rows_idx, D, dst=dhidden, scatter_add=True)
-        self.backward_from_hidden(dhidden, out["saved"])
+        if out["sel_rows"] is not None:
+            self.backward_from_hidden(dx, out["saved"])
+        else:
+            dhidden = torch.zeros((B * S, D), dtype=BF16, device=self.device)
+            ops.gather_rows(dx, rows_idx, D, dst=dhidden, scatter_add=True)
+            self.backward_from_hidden(dhidden, out["saved"])
         return loss_rows.sum().reshape(1), n_tok, pred
 
 
@@ -1123,8 +1167,8 @@ class ChunkGraph:
     def _run(self):
         eng = self.engine
         out = eng.forward_dev(self.ids, self.lab, self.lens, self.pixels, proprio=self.proprio, train=False,
-                              proprio_projector=self.proprio_projector)
-        ah, _ = eng.gather_action_hidden(out["hidden"], out["action_rows"])
+                              proprio_projector=self.proprio_projector, sel="actions")
+        ah, _ = eng.action_hidden(out)
         pred = self.head.fwd(ah)[0] if self.head is not None else None
         return pred, ah
 

@@ -417,9 +417,9 @@ class OpenVLAForActionPrediction(_StoreModule):
                 temb = action_head.time_encoder(torch.tensor([float(t)])).to(BF16)
                 out = self.engine.forward(ids, mask, pixel_values, labels, proprio=prop, train=False, noisy_actions=cur.to(BF16),
                                           timestep_emb=temb, proprio_projector=proprio_projector.comp if use_proprio else None,
-                                          noisy_action_projector=noisy_action_projector.comp, cached_patches=cached)
+                                          noisy_action_projector=noisy_action_projector.comp, cached_patches=cached, sel="actions")
                 cached = out["patches"]                                                   # vision features reused across steps (:810)
-                ah, _ = self.engine.gather_action_hidden(out["hidden"], out["action_rows"])
+                ah, _ = self.engine.action_hidden(out)
                 eps = action_head.predict_noise(ah.view(1, A, cfg.llm_dim)).reshape(cur.shape).float().cpu()
                 cur = sched.step(eps, int(t), cur).prev_sample.to(BF16).float()
             normalized = cur.reshape(cfg.chunk, cfg.action_dim).numpy()
@@ -442,8 +442,8 @@ class OpenVLAForActionPrediction(_StoreModule):
             ah = actions_hidden_states.view(A, cfg.llm_dim)
         else:
             out = self.engine.forward(ids, mask, pixel_values, labels, proprio=prop, train=False,
-                                      proprio_projector=proprio_projector.comp if use_proprio else None)
-            ah, _ = self.engine.gather_action_hidden(out["hidden"], out["action_rows"])   # rows P+NPT .. P+NPT+A-1 (:915-920)
+                                      proprio_projector=proprio_projector.comp if use_proprio else None, sel="actions")
+            ah, _ = self.engine.action_hidden(out)                                        # rows P+NPT .. P+NPT+A-1 (:915-920)
             actions_hidden_states = ah.view(1, A, cfg.llm_dim)
         if action_head is not None:                                                       # :923-927
             normalized = action_head.predict_action(actions_hidden_states).reshape(cfg.chunk, cfg.action_dim).float().cpu().numpy()

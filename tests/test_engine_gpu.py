@@ -172,3 +172,30 @@ def test_discrete_objective_matches_oracle(setup, dev):
     assert np.median(list(e_hip.values())) <= 1.5 * np.median(list(e_emu.values())) + 5e-3
     assert max(e_hip.values()) <= 2.0 * max(e_emu.values()) + 2e-2
     assert min(cos.values()) > 0.98
+
+
+def test_last_layer_on_selected_rows_equals_the_full_forward(setup):
+    """forward(sel="actions") runs the last decoder layer's attention-output projection, MLP and the final norm on the action rows
+    only (everything else of hidden_states[-1] is discarded by run_forward_pass / predict_action): same numbers as gathering those
+    rows from the full forward (different GEMM tile schedules at M = 168 vs 3 x S: equal to accumulation order), and the backward
+    through it gives the same gradients."""
+    eng, batch = setup["eng"], setup["batch"]
+    args = (batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["labels"])
+    full = eng.forward(*args, proprio=batch["proprio"], train=True)
+    ah_full, idx = eng.gather_action_hidden(full["hidden"], full["action_rows"])
+    sel = eng.forward(*args, proprio=batch["proprio"], train=True, sel="actions")
+    assert sel["hidden"] is None and sel["action_hidden"].shape == ah_full.shape and torch.equal(sel["sel_rows"], idx)
+    assert rel(sel["action_hidden"], ah_full) < 1e-2
+    g = torch.Generator(device="cpu").manual_seed(3)
+    dah = (torch.randn(ah_full.shape, generator=g) * 0.05).to(BF).to(eng.device)
+    eng.zero_grad()
+    dh = torch.zeros((full["hidden"].shape[0] * full["hidden"].shape[1], ah_full.shape[1]), dtype=BF, device=eng.device)
+    importlib.import_module("openvla-oft_amd.ops").gather_rows(dah, idx, ah_full.shape[1], dst=dh, scatter_add=True)
+    eng.backward_from_hidden(dh, full["saved"])
+    g_full = {k: v.float().clone() for k, v in eng.export_trainable("grad").items()}
+    eng.zero_grad()
+    eng.backward_from_hidden(dah, sel["saved"])
+    g_sel = eng.export_trainable("grad")
+    worst = max((((g_sel[k].float() - g_full[k]).norm() / (g_full[k].norm() + 1e-12)).item(), k) for k in g_full if g_full[k].norm() > 1e-7)
+    print(f"selected-rows backward vs full backward: worst rel-L2 {worst[0]:.3e} ({worst[1]})")
+    assert worst[0] < 2e-2
