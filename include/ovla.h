@@ -152,7 +152,7 @@ typedef struct {
   const void* Q; const void* K; const void* V; int64_t q_stride, k_stride, v_stride;
   const void* O; const void* dO; int64_t o_stride, do_stride;
   const float* lse;
-  float* delta;            /* workspace fp32 [B,H,S]: rowsum(dO * O) */
+  float* delta;            /* workspace fp32 [B,H,S]: rowsum(dO * O), written by the dQ kernel, read by the dK / dV kernel */
   void* dQ; void* dK; void* dV; int64_t dq_stride, dk_stride, dv_stride;
   const int32_t* kv_len;
   int32_t B, H, S, head_dim;

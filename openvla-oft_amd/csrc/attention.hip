@@ -242,34 +242,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
   }
 }
 
-// delta[b,h,s] = sum_d dO * O      (16 lanes per (row, head))
-__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnParams p) {
-  const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-  const int sub = threadIdx.x & 15;
-  const int64_t total = (int64_t)p.B * p.S * p.H;
-  float s = 0.f;
-  int64_t row = 0;
-  int h = 0;
-  if (item < total) {
-    row = item / p.H;
-    h = (int)(item % p.H);
-    const bf16_bits* o = p.O + row * p.o_stride + (int64_t)h * p.hd;
-    const bf16_bits* d = p.dO + row * p.do_stride + (int64_t)h * p.hd;
-    for (int c = sub * 8; c < p.hd; c += 128) {
-      const bf16x8_bits ov = *reinterpret_cast<const bf16x8_bits*>(o + c);
-      const bf16x8_bits dv = *reinterpret_cast<const bf16x8_bits*>(d + c);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += bf2f((bf16_bits)ov[j]) * bf2f((bf16_bits)dv[j]);
-    }
-  }
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (item < total && sub == 0) {
-    const int64_t bb = row / p.S, ss = row % p.S;
-    p.delta[(bb * p.H + h) * p.S + ss] = s;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // dQ: one workgroup per 64-query block, loops over K/V tiles.
 // Inverse RoPE (HF rotate_half convention) on one row's gradient held as DT = hd/16 accumulator tiles: lane (row = lane & 15,
@@ -327,7 +299,21 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParam
   }
   const int64_t stat = ((int64_t)b * p.H + h) * p.S + qrow_c;
   const float Lq = p.lse_in[stat] * LOG2E;
-  const float Dq = p.delta[stat];
+  // delta = rowsum(dO * O), computed here from the dO fragments the lane already holds (its 8-column chunks of the row; the four
+  // lane groups of a row cover every column) and written out for the dK / dV kernel, which runs after this one on the same stream
+  float Dq = 0.f;
+  {
+    const bf16_bits* Ob = p.O + (int64_t)b * p.S * p.o_stride + (int64_t)h * p.hd;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const bf16x8_bits of = gload8(Ob, p.o_stride, qrow_c, 32 * s + 8 * g, p.hd);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Dq += bf2f((bf16_bits)of[j]) * bf2f((bf16_bits)dof[s][j]);
+    }
+    Dq += __shfl_xor(Dq, 16, 64);
+    Dq += __shfl_xor(Dq, 32, 64);
+    if (g == 0 && qrow < p.S) p.delta[stat] = Dq;
+  }
   const float sl2 = p.scale * LOG2E;
 
   f32x4 accQ[DT];
@@ -638,9 +624,6 @@ extern "C" int ovla_attn_bwd(const ovla_attn_bwd_args* a, void* stream_) {
   p.lse_in = a->lse; p.delta = a->delta; p.kv_len = a->kv_len;
   p.B = a->B; p.H = a->H; p.S = a->S; p.hd = a->head_dim; p.causal = a->causal; p.scale = a->scale;
   p.rope_cos = (const bf16_bits*)a->rope_cos; p.rope_sin = (const bf16_bits*)a->rope_sin;
-  const int64_t items = (int64_t)a->B * a->S * a->H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(items, 16)), dim3(256), 0, stream, p);
-  OVLA_CHECK_LAUNCH("ovla_attn_bwd(delta)");
   const dim3 grid(cdiv(a->S, BQ), a->H, a->B);
   const dim3 grid_kv4(cdiv(a->S, 64), a->H, a->B), grid_kv8(cdiv(a->S, 128), a->H, a->B);
   switch (a->head_dim) {
