@@ -26,127 +26,117 @@ sys.path.insert(0, str(ROOT))
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
 
 
-def flops_per_sample(cfg, S, I):
-    """Executed algorithmic FLOPs of one train-step sample (SURVEY.md 8d formulas; the discarded last ViT block and the
-    lm_head/CE the reference computes and throws away in L1 mode are NOT executed and NOT counted)."""
+def flops_per_sample(cfg, S, I, sel_rows=None):
+    """Algorithmic FLOPs of one train-step sample (SURVEY.md 8d formulas) -> dict:
+      fwd / train          EXECUTED by this path: the discarded last ViT block and the lm_head + CE the reference computes and throws
+                           away in L1 mode are not run; with `sel_rows` (= A action rows per sample) the last decoder layer runs its
+                           o / gate|up / down projections on those rows only (LlamaStack.fwd(sel=...)), forward and data gradient;
+      fwd_ref / train_ref  REFERENCE-EQUIVALENT: what finetune.py:280-451 executes for the same step (all S rows in every layer,
+                           all `depth` ViT blocks in the forward, lm_head + cross entropy in the forward)."""
     D, F, L = cfg.llm_dim, cfg.llm_ff, cfg.llm_layers
     r = cfg.lora_rank
-    llm_lin = S * 2 * L * (4 * D * D + 3 * D * F)
+    qkv_lin, rest_lin = 2 * 3 * D * D, 2 * (D * D + 3 * D * F)             # per token per layer: q|k|v ; o + gate|up + down
+    qkv_lora, rest_lora = 2 * r * 3 * (D + D), 2 * r * ((D + D) + 2 * (D + F) + (F + D))
+    last_rows = S if sel_rows is None else sel_rows
+    llm_lin = S * (L - 1) * (qkv_lin + rest_lin) + S * qkv_lin + last_rows * rest_lin
+    lora_llm = S * (L - 1) * (qkv_lora + rest_lora) + S * qkv_lora + last_rows * rest_lora
+    llm_lin_ref, lora_llm_ref = S * L * (qkv_lin + rest_lin), S * L * (qkv_lora + rest_lora)
     llm_attn = 4 * L * S * S * D
-    lora_llm = S * 2 * L * r * (2 * D * 4 + 2 * (D + F) + (D + F))  # q,k,v,o: (D+D) each; gate,up: (D+F) each; down: (F+D)
-    vit = 0
+    vit = vit_last = 0
     for vc in (cfg.dino, cfg.siglip):
         T = vc.n_patches + vc.n_prefix
-        blocks = vc.depth - 1
-        vit += I * (2 * T * blocks * (4 * vc.dim * vc.dim + 2 * vc.dim * vc.mlp_hidden) + 4 * blocks * T * T * vc.dim
-                    + 2 * vc.n_patches * vc.patch_k * vc.dim)
+        blk = 2 * T * (4 * vc.dim * vc.dim + 2 * vc.dim * vc.mlp_hidden) + 4 * T * T * vc.dim
+        vit += I * ((vc.depth - 1) * blk + 2 * vc.n_patches * vc.patch_k * vc.dim)
+        vit_last += I * blk
     vd = cfg.vision_dim
     proj = 2 * I * cfg.dino.n_patches * (vd * 4 * vd + 4 * vd * D + D * D)
     head = 2 * cfg.chunk * (cfg.action_dim * D * D + 2 * D * D + D * cfg.action_dim)
+    lm_head = 2 * S * D * cfg.vocab
     fwd = llm_lin + llm_attn + vit + proj + head
     # frozen base: backward = data gradients only (= forward FLOPs) + attention backward (2.5x forward attention);
     # LoRA adds fwd + dgrad + wgrad of the skinny GEMMs; the head trains in full (fwd + dgrad + wgrad)
     train = 2 * (llm_lin + vit + proj) + 3.5 * llm_attn + 3 * lora_llm + 3 * head
-    return fwd, train
+    fwd_ref = llm_lin_ref + llm_attn + vit + vit_last + proj + head + lm_head
+    train_ref = 2 * (llm_lin_ref + vit + proj) + vit_last + lm_head + 3.5 * llm_attn + 3 * lora_llm_ref + 3 * head
+    return dict(fwd=fwd, train=train, fwd_ref=fwd_ref, train_ref=train_ref)
 
 
-def cpu_baseline(cfg, S, train_flops_per_sample):
-    """Times the CPU oracle (oracle/vla_oracle.py, kind "port") on a bounded slice of the same workload: one sample
-    (batch 1, S = 608) through ONE full-width Llama decoder layer + final norm + L1 head, forward + backward, fp32, all
-    host cores.  Its measured FLOP rate is converted to samples/s of the full step by the FLOP ratio."""
-    from oracle import vla_oracle as vo
-
-    # the threads this process may actually run on (a 1-GPU box grants a CPU share, not the host's whole core count:
-    # one thread per *granted* core; oversubscribing 256 threads onto 16 cores ran 10x slower)
+def _host_cores():
+    """The threads this process may actually run on (a 1-GPU box grants a CPU share, not the host's whole core count: one thread
+    per *granted* core; oversubscribing 256 threads onto 16 cores ran 10x slower)."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    quota = None
     try:   # cgroup v2 CPU quota, if any
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
         if q != "max":
-            quota = max(1, int(int(q) / int(per)))
+            cores = min(cores, max(1, int(int(q) / int(per))))
     except Exception:
         pass
-    if quota:
-        cores = min(cores, quota)
-    cores = min(cores, int(os.environ.get("OVLA_CPU_BASELINE_THREADS", "64")))
-    torch.set_num_threads(cores)
-    ocfg = vo.OracleConfig(llm_dim=cfg.llm_dim, llm_layers=1, llm_heads=cfg.llm_heads, llm_ff=cfg.llm_ff, vocab=cfg.vocab)
-    g = torch.Generator().manual_seed(0)
-    D, F, r = cfg.llm_dim, cfg.llm_ff, cfg.lora_rank
-    sd = {}
-
-    def lin(name, o, i, lora=True, bias=False):
-        sd[name + ".weight"] = torch.randn(o, i, generator=g) * 0.02
-        if bias:
-            sd[name + ".bias"] = torch.zeros(o)
-        if lora:
-            sd[name + ".lora_A.weight"] = (torch.randn(r, i, generator=g) / r).requires_grad_(True)
-            sd[name + ".lora_B.weight"] = (torch.randn(o, r, generator=g) * 0.01).requires_grad_(True)
-
-    p = "language_model.model.layers.0."
-    for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
-        lin(p + "self_attn." + n, D, D)
-    lin(p + "mlp.gate_proj", F, D); lin(p + "mlp.up_proj", F, D); lin(p + "mlp.down_proj", D, F)
-    sd[p + "input_layernorm.weight"] = torch.ones(D); sd[p + "post_attention_layernorm.weight"] = torch.ones(D)
-    sd["language_model.model.norm.weight"] = torch.ones(D)
-    hp = "action_head.model."
-    for nm, dim in (("layer_norm1", D * cfg.action_dim), ("layer_norm2", D), ("mlp_resnet_blocks.0.ffn.0", D), ("mlp_resnet_blocks.1.ffn.0", D)):
-        sd[hp + nm + ".weight"] = torch.ones(dim, requires_grad=True); sd[hp + nm + ".bias"] = torch.zeros(dim, requires_grad=True)
-    for nm, o, i in (("fc1", D, D * cfg.action_dim), ("mlp_resnet_blocks.0.ffn.1", D, D), ("mlp_resnet_blocks.1.ffn.1", D, D), ("fc2", cfg.action_dim, D)):
-        sd[hp + nm + ".weight"] = (torch.randn(o, i, generator=g) * 0.02).requires_grad_(True)
-        sd[hp + nm + ".bias"] = torch.zeros(o, requires_grad=True)
-    o = vo.Oracle(ocfg, sd, mode="fp32")
-    x = torch.randn(1, S, D, generator=g)
-    A = cfg.action_dim * cfg.chunk
-    tgt = torch.rand(1, cfg.chunk, cfg.action_dim, generator=g) * 2 - 1
-
-    def one():
-        h = o.llm(x, torch.ones(1, S, dtype=torch.bool))
-        pred = o.l1_head(h[:, S - 1 - A: S - 1])
-        (tgt - pred).abs().mean().backward()
-
-    one()  # warm-up (thread pool, allocator)
-    t0 = time.perf_counter()
-    reps = 0
-    while time.perf_counter() - t0 < 12.0:
-        one()
-        reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    lin_f = S * 2 * (4 * D * D + 3 * D * F)
-    attn_f = 4 * S * S * D
-    lora_f = S * 2 * r * (2 * D * 4 + 3 * (D + F))
-    head_f = 2 * cfg.chunk * (cfg.action_dim * D * D + 2 * D * D)
-    sample_flops = 2 * lin_f + 3.5 * attn_f + 3 * lora_f + 3 * head_f
-    rate = sample_flops / dt
-    return {"value": rate / train_flops_per_sample, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32 fwd+bwd of 1 sample (S={S}) through 1 of {cfg.llm_layers} full-width Llama layers + final norm + L1 head, "
-                      f"{reps} reps of {dt:.2f} s = {rate / 1e12:.3f} TFLOP/s, scaled by FLOPs to the full {train_flops_per_sample / 1e12:.1f} TFLOP/sample step"}
+    return min(cores, int(os.environ.get("OVLA_CPU_BASELINE_THREADS", "64")))
 
 
-def eager_baseline(cfg, batch_size, steps, warmup, dev):
-    """BASELINE.md B1: the same step executed by stock PyTorch-ROCm eager ops (hipBLASLt GEMMs, SDPA, unfused LoRA as
-    separate matmuls, torch.optim.AdamW, autograd), bf16 weights and activations, including the lm_head + fp32 logits +
-    cross-entropy that the reference computes and discards in L1 mode (finetune.py:338-351).  Runs the oracle's module
-    code in its "native" mode on the GPU: a timing baseline, not a parity reference."""
+def _oracle_cfg(cfg):
     from oracle import vla_oracle as vo
-    load = importlib.import_module
-    weights_mod, synth = load("openvla-oft_amd.weights"), load("openvla-oft_amd.synthetic")
-    sd = weights_mod.random_state_dict(cfg, dev, seed=0, lm_head=True)
-    # the towers' last block exists in the reference and runs although its output is discarded
+
+    vit_fields = ("dim", "depth", "heads", "mlp_hidden", "n_prefix", "layerscale", "patch", "image_size")
+    return vo.OracleConfig(**{f: getattr(cfg, f) for f in ("llm_dim", "llm_layers", "llm_heads", "llm_ff", "vocab", "rms_eps", "rope_theta",
+                                                           "num_images", "lora_rank", "lora_alpha", "action_dim", "chunk", "proprio_dim")},
+                           dino=vo.VitConfig(**{f: getattr(cfg.dino, f) for f in vit_fields}),
+                           siglip=vo.VitConfig(**{f: getattr(cfg.siglip, f) for f in vit_fields}))
+
+
+def cpu_baseline(cfg, sd_dev, b1, fl, gpu_chunks_per_s=None):
+    """SURVEY.md 8(d) "CPU baseline" = BASELINE.json configs[0] at full size: ONE action chunk (batch 1, 2 x 224 x 224 images +
+    proprio, S = 608, L1 head) through the CPU oracle (oracle/vla_oracle.py, kind "port": the reference itself cannot run on the GPU
+    box) in fp32 on the host cores this process is granted, full-size weights (the same seeded tensors as the GPU run, LoRA merged
+    away as in deployment, copied to host memory as fp32 before the clock starts).  ~8.9 TFLOP: about ten seconds on 16 cores.
+    The fine-tune metric's CPU figure is this measured FLOP rate applied to the train step's FLOPs (`train_step_estimate`)."""
+    from oracle import vla_oracle as vo
+
+    cores = _host_cores()
+    torch.set_num_threads(cores)
+    t_load = time.perf_counter()
+    sd = {k: v.float().cpu() for k, v in sd_dev.items() if ".lora_" not in k and not k.startswith("language_model.lm_head")}
+    t_load = time.perf_counter() - t_load
+    o = vo.Oracle(_oracle_cfg(cfg), sd, mode="fp32")
+    ids, am = b1["input_ids"][:, : -(cfg.num_action_tokens + 1)], b1["attention_mask"][:, : -(cfg.num_action_tokens + 1)]   # the prompt
+    pv, prop = b1["pixel_values"].float().cpu(), b1["proprio"].float().cpu().reshape(-1).numpy()
+    with torch.no_grad():
+        o.vit(pv[:, :3], "vision_backbone.featurizer.", o.cfg.dino)          # warm-up: thread pool, allocator (one tower, 0.16 TFLOP)
+        t0 = time.perf_counter()
+        actions, _ = o.predict_action(ids, am, pv, proprio=prop, head="l1")
+        dt = time.perf_counter() - t0
+    assert actions.shape == (cfg.chunk, cfg.action_dim) and bool((actions == actions).all())
+    rate = fl["fwd"] / dt
+    out = {"value": 1.0 / dt, "unit": "action-chunks/s (one batch-1 forward = one 8x7 chunk: BASELINE.json configs[0] at full size)", "cores": cores,
+           "kind": "port",
+           "sample": f"oracle fp32 predict_action, 1 chunk, S={b1['input_ids'].shape[1] + 1 + cfg.num_images * cfg.dino.n_patches}, all {cfg.llm_layers} layers + both towers "
+                     f"+ projector + L1 head at full size: {dt:.2f} s on {cores} threads = {rate / 1e12:.3f} TFLOP/s (weights copied to host as fp32 "
+                     f"beforehand: {t_load:.1f} s, not timed)",
+           "seconds_per_chunk": dt, "tflops": rate / 1e12,
+           "train_step_estimate": {"value": rate / fl["train_ref"], "unit": "samples/s",
+                                   "how": f"the measured CPU FLOP rate applied to the reference-equivalent {fl['train_ref'] / 1e12:.1f} TFLOP of one "
+                                          "fine-tune sample (an extrapolation, not a timed CPU train step)"}}
+    if gpu_chunks_per_s:
+        out["gpu_over_cpu_same_workload"] = gpu_chunks_per_s * dt
+    return out
+
+
+def _eager_state(cfg, sd):
+    """The bench's seeded weights as the stock-eager baseline needs them: the towers' last block exists in the reference and runs
+    although its output is discarded (blocks[depth-1] := a copy of blocks[depth-2])."""
+    sd = dict(sd)
     for prefix, vc in (("vision_backbone.featurizer.", cfg.dino), ("vision_backbone.fused_featurizer.", cfg.siglip)):
         src = f"{prefix}blocks.{vc.depth - 2}."
         for k in [k for k in sd if k.startswith(src)]:
-            sd[k.replace(src, f"{prefix}blocks.{vc.depth - 1}.")] = sd[k].clone()
-    trainable = [k for k in sd if ".lora_" in k or k.startswith(("action_head.", "proprio_projector."))]
-    for k in trainable:
-        sd[k].requires_grad_(True)
-    ocfg = vo.OracleConfig(**{f: getattr(cfg, f) for f in ("llm_dim", "llm_layers", "llm_heads", "llm_ff", "vocab", "rms_eps", "rope_theta",
-                                                          "num_images", "lora_rank", "lora_alpha", "action_dim", "chunk", "proprio_dim")},
-                           dino=vo.VitConfig(**{f: getattr(cfg.dino, f) for f in ("dim", "depth", "heads", "mlp_hidden", "n_prefix", "layerscale", "patch", "image_size")}),
-                           siglip=vo.VitConfig(**{f: getattr(cfg.siglip, f) for f in ("dim", "depth", "heads", "mlp_hidden", "n_prefix", "layerscale", "patch", "image_size")}))
+            sd[k.replace(src, f"{prefix}blocks.{vc.depth - 1}.")] = sd[k]
+    return sd
+
+
+def _full_depth_oracle():
+    from oracle import vla_oracle as vo
 
     class FullDepth(vo.Oracle):   # run ALL ViT blocks like timm does (the oracle skips the discarded one)
         def vit(self, img, prefix, vc, film_avg=None):
@@ -162,7 +152,23 @@ def eager_baseline(cfg, batch_size, steps, warmup, dev):
             self._dead = x + self.linear(self.act(self.linear(h, p + "mlp.fc1")), p + "mlp.fc2")
             return out
 
-    o = FullDepth(ocfg, sd, mode="native")
+    return FullDepth
+
+
+def eager_baseline(cfg, batch_size, steps, warmup, dev, sd=None):
+    """BASELINE.md B1: the same step executed by stock PyTorch-ROCm eager ops (hipBLASLt GEMMs, SDPA, unfused LoRA as
+    separate matmuls, torch.optim.AdamW, autograd), bf16 weights and activations, including the lm_head + fp32 logits +
+    cross-entropy that the reference computes and discards in L1 mode (finetune.py:338-351).  Runs the oracle's module
+    code in its "native" mode on the GPU: a timing baseline, not a parity reference."""
+    load = importlib.import_module
+    weights_mod, synth = load("openvla-oft_amd.weights"), load("openvla-oft_amd.synthetic")
+    if sd is None:
+        sd = weights_mod.random_state_dict(cfg, dev, seed=0, lm_head=True)
+    sd = _eager_state(cfg, sd)
+    trainable = [k for k in sd if ".lora_" in k or k.startswith(("action_head.", "proprio_projector."))]
+    for k in trainable:
+        sd[k] = sd[k].detach().clone().requires_grad_(True)
+    o = _full_depth_oracle()(_oracle_cfg(cfg), sd, mode="native")
     opt = torch.optim.AdamW([sd[k] for k in trainable], lr=5e-4)
     batch = synth.make_batch(batch_size, seed=1000)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
@@ -189,6 +195,7 @@ def eager_baseline(cfg, batch_size, steps, warmup, dev):
         return r
 
     o.multimodal_hidden = keep
+    torch.cuda.reset_peak_memory_stats()
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -197,8 +204,52 @@ def eager_baseline(cfg, batch_size, steps, warmup, dev):
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"kind": "torch-eager (stock PyTorch-ROCm ops, bf16, hipBLASLt + SDPA + torch.optim.AdamW)", "ms_per_step": 1e3 * dt,
-            "samples_per_s": batch_size / dt, "loss": loss.item(), "peak_mem_gib": torch.cuda.max_memory_allocated() / 2**30}
+    return {"kind": "B1: torch-eager (stock PyTorch-ROCm ops, bf16, hipBLASLt + SDPA + autograd + torch.optim.AdamW; the oracle's modules in mode='native')",
+            "ms_per_step": 1e3 * dt, "samples_per_s": batch_size / dt, "steps": steps, "warmup": warmup, "loss": loss.item(),
+            "peak_mem_gib": torch.cuda.max_memory_allocated() / 2**30}
+
+
+def eager_inference_baseline(cfg, dev, sd, b1, n=20):
+    """one predict_action-equivalent forward (batch 1, L1 head) by stock PyTorch-ROCm eager ops on the merged
+    (adapter-free) weights the reference deploys, all ViT blocks, no lm_head (the L1 branch of predict_action does not call it:
+    modeling_prismatic.py:879-927)."""
+    sd = {k: v for k, v in _eager_state(cfg, sd).items() if ".lora_" not in k}
+    o = _full_depth_oracle()(_oracle_cfg(cfg), sd, mode="native")
+    b = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b1.items()}
+    pv, prop = b["pixel_values"].to(torch.bfloat16), b["proprio"].to(torch.bfloat16)
+
+    def once():
+        with torch.no_grad():
+            hidden, P = o.multimodal_hidden(b["input_ids"], b["attention_mask"], pv, b["labels"], prop)
+            A = cfg.num_action_tokens
+            ah = hidden[:, -(A + 1): -1]                       # rows that predict the action slots (shift by one; stop is the last id)
+            return o.l1_head(ah)
+
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        r = once()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / n
+    assert tuple(r.shape) == (1, cfg.chunk, cfg.action_dim)
+    return {"kind": "B3: torch-eager batch-1 chunk (stock PyTorch-ROCm ops, bf16, merged weights)", "ms_per_chunk": ms, "chunks_per_s": 1e3 / ms, "reps": n}
+
+
+def measured_traffic(tiny: bool):
+    """`roofline.traffic`: HBM-side bytes per launch of the dominant kernel from PMC counters.  They cannot be collected from inside
+    this process (rocprofv3 --pmc passes; tools/pmc_traffic.sh + tools/pmc_traffic_parse.py write profiles/pmc_traffic.json), so the
+    value is read from that file together with where it came from; it is flagged stale when gemm_nt.hip has changed since."""
+    import hashlib
+
+    f = ROOT / "profiles" / "pmc_traffic.json"
+    if tiny or not f.exists():
+        return None, {"traffic_source": None}
+    rec = json.loads(f.read_text())
+    sha = hashlib.sha256((ROOT / "openvla-oft_amd" / "csrc" / "gemm_nt.hip").read_bytes()).hexdigest()[:16]
+    return rec["bytes_per_launch"], {"traffic_source": rec.get("source"), "traffic_algorithmic_bytes": rec.get("algorithmic_bytes"),
+                                     "traffic_shape_mnk": rec.get("shape"), "traffic_stale": rec.get("gemm_nt_sha16") != sha}
 
 
 def main():
@@ -209,6 +260,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (reference recipe: 8, LIBERO.md:91-113)")
     ap.add_argument("--tiny", action="store_true", help="reduced-size model (plumbing check only; NOT a valid benchmark number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eager-baseline", action="store_true", help="skip the in-process stock PyTorch-ROCm eager legs (BASELINE.md B1 and B3)")
+    ap.add_argument("--baseline-steps", type=int, default=10, help="timed steps of the B1 eager leg (after 3 warm-up steps)")
     ap.add_argument("--no-inference", action="store_true", help="skip the batch-1 inference leg (configs[1])")
     ap.add_argument("--aloha", action="store_true", help="SURVEY.md 8(d) config 5 instead of the headline workload: ALOHA shapes (3 images, 25x14 "
                     "chunk, proprio 14, S=1159), FiLM + diffusion head, batch 4 -- a side measurement, not the BASELINE metric")
@@ -251,6 +304,7 @@ def main():
             args.batch = 4           # ALOHA.md:69
     if args.eager_baseline:
         res = eager_baseline(cfg, args.batch, args.steps, args.warmup, dev)
+        res.pop("steps"), res.pop("warmup")
         print(json.dumps({"metric": "fine-tune samples/s (action-chunks/s) OpenVLA-7B bf16 [torch eager baseline]", "value": res["samples_per_s"],
                           "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, **res}))
         return
@@ -339,13 +393,13 @@ def main():
         dom = max(gemms, key=lambda k: gemms[k][1])
         n, ms, fl = gemms[dom]
         achieved = fl / (ms * 1e-3) / 1e12
+        traffic, traffic_info = measured_traffic(args.tiny)
         all_n, all_ms, all_fl = (sum(v[i] for v in gemms.values()) for i in range(3))
         roofline = {"bound": "mfma", "kernel": inst.get(dom, dom) + " (bf16 NT GEMM + LoRA K-extension + fused epilogue; incl. its hybrid-remainder reduce)",
                     "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                    # HBM-side bytes per launch from PMC counters cannot be collected from inside this process; the value below is
-                    # the measured, gfx950-corrected FETCH_SIZE*2 + WRITE_SIZE of the most expensive shape (gate|up forward,
-                    # 4864x22016x4096; 4.34e8 algorithmic bytes), see profiles/r01_pmc_gemm_gate_up.md
-                    "traffic": 1.62e9 if not args.tiny else None,
+                    # HBM-side bytes per launch (PMC, gfx950-corrected FETCH_SIZE*2 + WRITE_SIZE) of the most expensive shape:
+                    # read from profiles/pmc_traffic.json (measured_traffic)
+                    "traffic": traffic, **traffic_info,
                     "launches_per_step": n, "avg_launch_us": 1e3 * ms / n, "flops_per_step": fl, "ms_per_step": ms,
                     "all_gemm_nt": {"launches": all_n, "ms": all_ms, "flops_per_step": all_fl, "tflops": all_fl / (all_ms * 1e-3) / 1e12,
                                     "by_instance": {inst.get(k, k): {"launches": v[0], "ms": v[1], "tflops": v[2] / (v[1] * 1e-3) / 1e12}
@@ -353,19 +407,23 @@ def main():
                     "other_kernels": {k: {"launches": v[0], "ms": v[1], "tflops": (v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else None)}
                                       for k, v in fam.items() if not k.startswith("gemm_nt")},
                     "event_timed_ms_per_step": sum(v[1] for v in fam.values())}
-        fwd_f, train_f = flops_per_sample(cfg, S, cfg.num_images)
-        roofline["step_tflops_per_sample"] = train_f / 1e12
-        roofline["step_mfma_frac"] = (train_f * args.batch / (ms_per_step * 1e-3)) / 1e12 / PEAK_BF16_TFLOPS
-        if not args.no_cpu_baseline and not args.tiny and world == 1:   # the CPU baseline is reported at N = 1 only
-            cpu = cpu_baseline(cfg, S, train_f)
+        sel_on = os.environ.get("OVLA_LAST_LAYER_SEL", "1") != "0" and (args.batch * cfg.num_action_tokens) % 8 == 0
+        flp = flops_per_sample(cfg, S, cfg.num_images, sel_rows=cfg.num_action_tokens if sel_on else None)
+        # skipped work leaves the count -- the fraction is priced on EXECUTED FLOPs; the reference-equivalent count
+        # (every row in the last layer, all ViT blocks, lm_head + CE) is reported beside it
+        roofline["step_tflops_per_sample"] = flp["train"] / 1e12
+        roofline["step_tflops_per_sample_reference_equivalent"] = flp["train_ref"] / 1e12
+        roofline["step_mfma_frac"] = (flp["train"] * args.batch / (ms_per_step * 1e-3)) / 1e12 / PEAK_BF16_TFLOPS
+        roofline["step_mfma_frac_reference_equivalent"] = (flp["train_ref"] * args.batch / (ms_per_step * 1e-3)) / 1e12 / PEAK_BF16_TFLOPS
     # ---- BASELINE.json configs[1]: single-chunk inference, batch 1; rank 0 only, no collectives.  Runs LAST on the training
     # engine: (1) adapters applied on the fly (the state during fine-tuning evaluation), (2) adapters merged into the base
     # weights as the reference deploys them (merge_lora_weights_and_save.py), (3) the merged forward replayed from a hipGraph.
     infer = None
-    if rank == 0 and not args.no_inference and not args.aloha:
+    if rank == 0 and not args.aloha:
         b1 = synth.make_batch(1, seed=77, num_images=cfg.num_images, chunk=cfg.chunk, action_dim=cfg.action_dim, proprio_dim=cfg.proprio_dim)
         b1["pixel_values"] = b1["pixel_values"].to(dev, torch.bfloat16)
         b1["proprio"] = b1["proprio"].to(dev, torch.bfloat16).reshape(1, -1)
+    if rank == 0 and not args.no_inference and not args.aloha:
 
         def infer_once():
             out = eng.forward(b1["input_ids"], b1["attention_mask"], b1["pixel_values"], b1["labels"], proprio=b1["proprio"], train=False,
@@ -401,6 +459,27 @@ def main():
                  "mode": "LoRA merged (W += 0.5 B A on device) + hipGraph replay",
                  "ms_per_chunk_merged_eager": ms_merged, "ms_per_chunk_unmerged_eager": ms_lora}
 
+    # ---- measured baselines, same process, same box, AFTER every timed region (rank 0, N = 1 only):
+    #   B1  stock PyTorch-ROCm eager fine-tune step (the denominator of north_star's ">= 1.5x" target), B3 stock eager batch-1 chunk,
+    #   cpu_baseline  the CPU oracle on one full-size chunk (BASELINE.json configs[0] at full size)
+    baselines = None
+    if rank == 0 and world == 1 and not args.tiny and not args.aloha and not (args.no_eager_baseline and args.no_cpu_baseline):
+        graph = None
+        torch.cuda.empty_cache()
+        sd0 = weights_mod.random_state_dict(cfg, dev, seed=0, lm_head=True)      # the same seeded tensors the engine was built from
+        if not args.no_eager_baseline:
+            e1 = eager_baseline(cfg, args.batch, args.baseline_steps, 3, dev, sd=sd0)
+            torch.cuda.empty_cache()
+            e3 = eager_inference_baseline(cfg, dev, sd0, b1)
+            baselines = {"B1_torch_eager_train_step": e1, "B3_torch_eager_inference_batch1": e3,
+                         "speedup_vs_B1": value / e1["samples_per_s"],
+                         "speedup_vs_B3": (infer["chunks_per_s"] / e3["chunks_per_s"]) if infer else None,
+                         "note": "BASELINE.md publishes no number for this metric (vs_baseline stays null); B1 / B3 are BASELINE.md section 2's "
+                                 "self-measured baselines, run in this process on this GPU after the timed region"}
+            torch.cuda.empty_cache()
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(cfg, sd0, b1, flp, infer["chunks_per_s"] if infer else None)
+        del sd0
     if world > 1:
         dist.barrier()
     if rank == 0:
@@ -412,7 +491,7 @@ def main():
                                     "BASELINE.json configs[2]: LoRA r=32 fine-tune step (fwd+bwd+AdamW), 2x224x224 images + proprio, L1 head") + (" [TINY MODEL - not a benchmark]" if args.tiny else ""),
                        "global_batch": world * args.batch, "seq_len": S, "parallelism": f"dp{world}", "mask_mode": cfg.mask_mode,
                        "final_loss": final_loss},
-            "roofline": roofline, "cpu_baseline": cpu, "inference_batch1": infer}))
+            "roofline": roofline, "cpu_baseline": cpu, "inference_batch1": infer, "measured_baselines": baselines}))
     if world > 1:
         dist.destroy_process_group()
 
