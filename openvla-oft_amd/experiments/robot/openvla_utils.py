@@ -46,8 +46,23 @@ def find_checkpoint_file(pretrained_checkpoint: str, file_pattern: str) -> str:
     return files[0]
 
 
+def platform_model_config(model_config: VLAConfig = OPENVLA_7B, num_images: Optional[int] = None) -> VLAConfig:
+    """The architecture config with the robot platform's constants filled in from prismatic.vla.constants, which is where the
+    reference reads them everywhere (ACTION_DIM / NUM_ACTIONS_CHUNK in modeling_prismatic.py:36-44, the normalisation type in
+    :772-791 and openvla_utils.py:645-675): LIBERO 8 x 7 / proprio 8 / q01-q99 bounds, ALOHA 25 x 14 / proprio 14 / min-max bounds."""
+    import dataclasses
+
+    kw = dict(action_dim=C.ACTION_DIM, chunk=C.NUM_ACTIONS_CHUNK, proprio_dim=C.PROPRIO_DIM, norm_type=C.ACTION_PROPRIO_NORMALIZATION_TYPE.value)
+    if num_images is not None:
+        kw["num_images"] = int(num_images)
+    return dataclasses.replace(model_config, **kw)
+
+
 def get_vla(cfg: Any, model_config: VLAConfig = OPENVLA_7B) -> OpenVLAForActionPrediction:
-    """Loads the HF-layout checkpoint shards of `cfg.pretrained_checkpoint` (safetensors) into the HIP engine."""
+    """Loads the HF-layout checkpoint shards of `cfg.pretrained_checkpoint` (safetensors) into the HIP engine.  Action / proprio
+    dimensions and the un-normalisation rule follow prismatic.vla.constants (the active platform), like get_action_head /
+    get_proprio_projector / normalize_proprio below and finetune()."""
+    model_config = platform_model_config(model_config, getattr(cfg, "num_images_in_input", None))
     ckpt = Path(cfg.pretrained_checkpoint)
     if not ckpt.is_dir():
         raise ValueError(f"`{ckpt}` is not a local checkpoint directory (HF-hub checkpoints cannot be fetched offline)")
