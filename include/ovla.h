@@ -33,6 +33,9 @@ extern "C" {
 
 const char* ovla_last_error(void);
 int ovla_abi_version(void);
+/* sha256 (first 32 hex digits) of the sources, headers and build script this library was compiled from (csrc/build.sh); the Python
+ * loader compares it with the files next to the library and refuses a stale build. */
+const char* ovla_build_hash(void);
 /* Checks that `device` is a gfx950 part; returns OVLA_OK / OVLA_EARCH / OVLA_ELAUNCH. */
 int ovla_check_device(int device);
 
@@ -293,6 +296,15 @@ int ovla_film_bwd(const ovla_film_bwd_args* a, void* stream);
 /* mean pooling:  out[b,:] = mean over rows i with row_mask[b,i] != 0 of x[b, i, :]  (FiLM's average language embedding) */
 typedef struct { const void* x; const uint8_t* row_mask; void* out; int32_t B, L, dim; } ovla_masked_mean_args;
 int ovla_masked_mean(const ovla_masked_mean_args* a, void* stream);
+
+/* FiLM's conditioning vector straight from the token ids (modeling_prismatic.py:575-583: `input_embeddings[~all_actions_mask]`
+ * averaged over the sequence, film_vit_wrapper.py:243): out[b,:] = bf16(mean_i embed[ids[b,i], :]) over the text positions i whose label
+ * is NOT an action token (labels[b,i] <= action_token_begin, which includes IGNORE_INDEX: BOS, prompt, stop and pad positions all
+ * count, as in the reference).  The action mask is the same integer rule as ovla_assemble_multimodal's (an action token is always a
+ * counted label, so the cumulative-count clause of train_utils.py:8-39 cannot change it).  fp32 sum of the bf16 rows, one rounding.
+ * ids / labels int64 [B, L]; embed bf16 [vocab, D]; out bf16 [B, D].  No host synchronisation: capturable in a hipGraph. */
+typedef struct { const int64_t* ids; const int64_t* labels; const void* embed_table; void* out; int32_t B, L, D, vocab; int64_t action_token_begin; } ovla_language_average_args;
+int ovla_language_average(const ovla_language_average_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Multimodal sequence assembly (modeling_prismatic.py:571-629): one pass writes

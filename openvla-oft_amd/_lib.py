@@ -13,7 +13,7 @@ from pathlib import Path
 _PKG_DIR = Path(__file__).resolve().parent
 _REPO_ROOT = _PKG_DIR.parent
 HEADER_PATH = _REPO_ROOT / "include" / "ovla.h"
-LIB_PATH = _PKG_DIR / "libovla_hip.so"
+LIB_PATH = _PKG_DIR / os.environ.get("OVLA_LIB_NAME", "libovla_hip.so")   # tools/gemm_ablate.py loads libovla_hip_ablate.so
 
 _CTYPE = {
     "void*": ctypes.c_void_p,
@@ -95,6 +95,18 @@ for _name, _fields in STRUCT_FIELDS.items():
 _lib = None
 
 
+def source_hash() -> str:
+    """The hash csrc/build.sh compiles into the library: sha256 over csrc/*.hip + csrc/*.h (C-locale name order), build.sh, ovla.h."""
+    import hashlib
+
+    csrc = _PKG_DIR / "csrc"
+    names = sorted([f.name for f in csrc.glob("*.hip")] + [f.name for f in csrc.glob("*.h")])
+    h = hashlib.sha256()
+    for f in [csrc / n for n in names] + [csrc / "build.sh", HEADER_PATH]:
+        h.update(f.read_bytes())
+    return h.hexdigest()[:32]
+
+
 def lib() -> ctypes.CDLL:
     """Loads libovla_hip.so; raises if it has not been built (no CPU / eager fallback exists)."""
     global _lib
@@ -116,6 +128,10 @@ def lib() -> ctypes.CDLL:
         fn.argtypes = [ctypes.POINTER(STRUCTS[t]) if kind == "struct" else _CTYPE[t] for kind, t in argtypes]
     if handle.ovla_abi_version() != 1:
         raise RuntimeError("libovla_hip.so ABI version mismatch")
+    built, want = handle.ovla_build_hash().decode(), source_hash()
+    if built != want:
+        raise RuntimeError(f"{LIB_PATH.name} is STALE: it was built from sources with hash {built}, the sources beside it hash to {want}. "
+                           f"Rebuild with {_PKG_DIR / 'csrc' / 'build.sh'} (there is no fallback path).")
     _lib = handle
     return handle
 

@@ -14,6 +14,10 @@ void ovla_set_error(const char* fmt, ...) {
 
 extern "C" const char* ovla_last_error(void) { return g_err; }
 extern "C" int ovla_abi_version(void) { return OVLA_ABI_VERSION; }
+#ifndef OVLA_SRC_HASH
+#define OVLA_SRC_HASH "unhashed"
+#endif
+extern "C" const char* ovla_build_hash(void) { return OVLA_SRC_HASH; }
 
 extern "C" int ovla_check_device(int device) {
   hipDeviceProp_t prop;

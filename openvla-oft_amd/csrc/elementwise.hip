@@ -411,6 +411,26 @@ __global__ __launch_bounds__(256) void masked_mean_kernel(const bf16_bits* __res
   out[(int64_t)b * dim + col] = f2bf(s / (float)(cnt > 0 ? cnt : 1));
 }
 
+// out[b, :] = mean over text positions i with labels[b,i] <= action_token_begin of embed[ids[b,i], :]   (FiLM conditioning vector)
+__global__ __launch_bounds__(256) void language_average_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ labels,
+                                                               const bf16_bits* __restrict__ embed, bf16_bits* __restrict__ out, int L, int D,
+                                                               int vocab, int64_t action_token_begin) {
+  const int b = blockIdx.y;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= D) return;
+  float s = 0.f;
+  int cnt = 0;
+  for (int i = 0; i < L; ++i) {
+    if (labels[(int64_t)b * L + i] <= action_token_begin) {
+      int64_t id = ids[(int64_t)b * L + i];
+      id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);      // same clamp as the assembly kernel: never read outside the table
+      s += bf2f(embed[id * D + col]);
+      ++cnt;
+    }
+  }
+  out[(int64_t)b * D + col] = f2bf(s / (float)(cnt > 0 ? cnt : 1));
+}
+
 // FiLM backward: one thread per (batch, column), walking the batch's rows (coalesced across the 256 columns of a block).
 __global__ __launch_bounds__(256) void film_bwd_kernel(bf16_bits* __restrict__ dy, const bf16_bits* __restrict__ x_pre,
                                                        const bf16_bits* __restrict__ gamma, float* __restrict__ dgamma,
@@ -1114,6 +1134,15 @@ extern "C" int ovla_masked_mean(const ovla_masked_mean_args* a, void* stream_) {
   hipLaunchKernelGGL(masked_mean_kernel, dim3(cdiv(a->dim, 256), a->B), dim3(256), 0, stream, (const bf16_bits*)a->x, a->row_mask,
                      (bf16_bits*)a->out, a->B, a->L, a->dim);
   OVLA_CHECK_LAUNCH("ovla_masked_mean");
+  return OVLA_OK;
+}
+extern "C" int ovla_language_average(const ovla_language_average_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->ids && a->labels && a->embed_table && a->out, "ovla_language_average: null pointer");
+  OVLA_REQUIRE(a->B > 0 && a->L > 0 && a->D > 0 && a->vocab > 0, "ovla_language_average: bad shape B=%d L=%d D=%d vocab=%d", a->B, a->L, a->D, a->vocab);
+  hipLaunchKernelGGL(language_average_kernel, dim3(cdiv(a->D, 256), a->B), dim3(256), 0, stream, a->ids, a->labels, (const bf16_bits*)a->embed_table,
+                     (bf16_bits*)a->out, a->L, a->D, a->vocab, a->action_token_begin);
+  OVLA_CHECK_LAUNCH("ovla_language_average");
   return OVLA_OK;
 }
 extern "C" int ovla_assemble_multimodal(const ovla_assemble_args* a, void* stream_) {

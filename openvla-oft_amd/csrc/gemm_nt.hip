@@ -26,6 +26,14 @@ constexpr int BK = 64;
 
 __device__ __attribute__((aligned(16))) bf16_bits g_ovla_zero_chunk[8];
 
+// Timing ablations are not part of the product kernel: in the default build OVLA_DBG(bit) is the constant 0 and every ablation branch
+// folds away; `build.sh ablate` compiles a separate library with -DOVLA_GEMM_ABLATE where it tests GemmParams::dbg (= args.tile / 1000).
+#ifdef OVLA_GEMM_ABLATE
+#define OVLA_DBG(bit) (p.dbg & (bit))
+#else
+#define OVLA_DBG(bit) 0
+#endif
+
 struct GemmParams {
   const bf16_bits *A, *B, *A2, *B2;
   int64_t lda, ldb, lda2, ldb2;
@@ -43,7 +51,7 @@ struct GemmParams {
   const bf16_bits* dact_src; int64_t ld_dact; int dact_mode, dact_act;   // backward epilogues (ovla.h)
   const bf16_bits *rope_cos, *rope_sin; int rope_S, rope_cols;           // forward RoPE on columns [0, rope_cols), head_dim 128
   int fast_epi;  // host: no FiLM / backward epilogue / RoPE and 16-byte aligned operands -> the unrolled read-back path applies
-  int dbg;  // timing ablations (tools/gemm_ablate.py): bit0 = stage only the first two K tiles, bit1 = read fragments once, bit2 = every workgroup stages tile (0,0): all L2 hits, bit3 = no epilogue, bit4 = epilogue without its stores, bit5 = nontemporal stores, bit6 = force the LDS-staged epilogue
+  int dbg;  // timing ablations, compiled in ONLY with -DOVLA_GEMM_ABLATE (build.sh ablate -> libovla_hip_ablate.so, tools/gemm_ablate.py): bit0 = stage only the first two K tiles, bit1 = read fragments once, bit2 = every workgroup stages tile (0,0): all L2 hits, bit3 = no epilogue, bit4 = epilogue without its stores, bit5 = nontemporal stores, bit6 = force the LDS-staged epilogue
   int full_tiles, rem_tiles, rem_splits;  // hybrid schedule: tiles >= full_tiles are split rem_splits ways along K
 };
 
@@ -174,8 +182,8 @@ OVLA_DEV void epilogue_store(const GemmParams& p, int m, int n, f32x4 v) {
   bf16x4_bits o;
 #pragma unroll
   for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(v[j]);
-  if ((p.dbg & 16) && v[0] != 123.456f) return;            // timing ablation: the whole epilogue except the store
-  if (p.dbg & 32) {                                          // timing ablation: write-through store that does not stay in this XCD's L2
+  if (OVLA_DBG(16) && v[0] != 123.456f) return;            // timing ablation: the whole epilogue except the store
+  if (OVLA_DBG(32)) {                                          // timing ablation: write-through store that does not stay in this XCD's L2
     __builtin_nontemporal_store(o, reinterpret_cast<bf16x4_bits*>(p.C + (int64_t)m * p.ldc + n));
     return;
   }
@@ -269,8 +277,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   uint32_t offA[BM / 8 / NW], offB[BN / 8 / NW];
-  stage_offsets<BM, NW>(offA, p.lda, (p.dbg & 4) ? 0 : m0, p.M - 1, wave, lane);
-  stage_offsets<BN, NW>(offB, p.ldb, (p.dbg & 4) ? 0 : n0, p.N - 1, wave, lane);
+  stage_offsets<BM, NW>(offA, p.lda, OVLA_DBG(4) ? 0 : m0, p.M - 1, wave, lane);
+  stage_offsets<BN, NW>(offB, p.ldb, OVLA_DBG(4) ? 0 : n0, p.N - 1, wave, lane);
   const int t_fast = p.fast_addr ? p.K / BK : 0;   // K tiles that lie entirely inside [0, K): no zero-chunk select needed
 
   auto stage = [&](int t, int buf) {
@@ -313,9 +321,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA for tile t has landed
     __syncthreads();                                   // ... everyone's has; and buf^1 is no longer being read
     if constexpr (!SPREAD) {
-      if (t + 1 < t_end && !((p.dbg & 1) && t > t_begin)) stage(t + 1, buf ^ 1);
+      if (t + 1 < t_end && !(OVLA_DBG(1) && t > t_begin)) stage(t + 1, buf ^ 1);
     }
-    const bf16_bits* sA = smem + ((p.dbg & 2) ? 0 : buf) * TILE_ELEMS;
+    const bf16_bits* sA = smem + (OVLA_DBG(2) ? 0 : buf) * TILE_ELEMS;
     const bf16_bits* sB = sA + BM * BK;
     bf16_bits* nA = smem + (buf ^ 1) * TILE_ELEMS;
     bf16_bits* nB = nA + BM * BK;
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   {
     const int lim = t_end < t_fast ? t_end : t_fast;   // spread loop: tile t+1 exists and is a fast-address tile
     if constexpr (NW >= 8) {   // 4-wave configs run 2 workgroups per CU, which already interleave; spreading only costs them
-      if (!(p.dbg & 1))
+      if (!OVLA_DBG(1))
         for (; t + 1 < lim; ++t) tile_body(t, std::true_type{});
     }
   }
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   for (int j = 0; j < NT; ++j)
     acc[MT - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a_def, acc[MT - 1][j], 0, 0, 0);
 
-  if (p.dbg & 8) {   // timing ablation: no epilogue at all (one store per lane keeps the accumulators alive)
+  if (OVLA_DBG(8)) {   // timing ablation: no epilogue at all (one store per lane keeps the accumulators alive)
     if (acc[0][0][0] == 123.456f) p.C[0] = 1;
     return;
   }
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   // (the 256x256 configs hold 128 accumulator registers: unrolling the activation code there spills, and no 256x256-tiled GEMM of
   // this model has an activation -- those keep the alpha / bias / residual subset)
   constexpr bool FAST_ACT = MT * NT <= 16;
-  if (p.fast_epi && (FAST_ACT || (p.act == OVLA_ACT_NONE && !p.Cpre && !p.colscale)) && !(p.dbg & 64) && m0 + BM <= p.M && n0 + BN <= p.N &&
+  if (p.fast_epi && (FAST_ACT || (p.act == OVLA_ACT_NONE && !p.Cpre && !p.colscale)) && !OVLA_DBG(64) && m0 + BM <= p.M && n0 + BN <= p.N &&
       (WTN % 8) == 0) {
     constexpr int OCT = WTN / 8;                 // 8-column groups per slab row
     constexpr int STEPS = RM * 16 * OCT / 64;    // read-back steps per round
@@ -492,7 +500,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
         bf16x8_bits o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(x[e]);
-        if (p.dbg & 32) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n));
+        if (OVLA_DBG(32)) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n));
         else *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
       }
       }
@@ -1080,7 +1088,12 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   p.T1 = cdiv(p.K, BK); p.T2 = p.K2 > 0 ? cdiv(p.K2, BK) : 0;
   if (p.split_k > p.T1 + p.T2) p.split_k = p.T1 + p.T2;
   p.full_tiles = 0; p.rem_tiles = 0; p.rem_splits = 1;
+#ifdef OVLA_GEMM_ABLATE
   p.dbg = (a->tile >= 1000) ? (a->tile / 1000) : 0;
+#else
+  OVLA_REQUIRE(a->tile < 1000, "ovla_gemm_bf16: tile %d selects a timing ablation; this library was built without OVLA_GEMM_ABLATE", a->tile);
+  p.dbg = 0;
+#endif
   p.fast_epi = !a->film_gamma && !a->dact_src && !a->rope_cos && (!a->C_pre || (((uintptr_t)a->C_pre) & 15) == 0) &&
                (!a->colscale || (((uintptr_t)a->colscale) & 15) == 0) &&
                (!a->residual || ((((uintptr_t)a->residual) & 15) == 0 && (a->ldr % 8) == 0)) && (!a->bias || (((uintptr_t)a->bias) & 15) == 0);

@@ -891,19 +891,14 @@ class VLAEngine:
         return self._side
 
     # -- the training step pieces -------------------------------------------------------------------------------------------
-    def language_average(self, ids_dev, labels_cpu):
+    def language_average(self, ids_dev, lab_dev):
         """FiLM conditioning vector: mean of the token embeddings at every NON-action position of the text (BOS, prompt,
         stop AND pad tokens: modeling_prismatic.py:581-583 averages `input_embeddings[~all_actions_mask]`;
-        film_vit_wrapper.py:243).  Returned padded to a multiple of 8 rows (GEMM M granularity of the FiLM Linears)."""
-        cfg = self.cfg
-        B, L = ids_dev.shape
-        cum = torch.cumsum(labels_cpu != -100, dim=1)
-        amask = (labels_cpu > 31743) & (cum >= 1)                        # train_utils.py:8-39 (host-side integer logic)
-        keep = (~amask).to(torch.uint8).to(self.device).contiguous()
-        emb = ops.gather_rows(self.embed, ids_dev.reshape(-1).to(torch.int32).contiguous(), cfg.llm_dim)
-        avg = torch.zeros(((B + 7) // 8 * 8, cfg.llm_dim), dtype=BF16, device=self.device)
-        avg[:B] = ops.masked_mean(emb, keep, B, L, cfg.llm_dim)
-        return avg
+        film_vit_wrapper.py:243).  One kernel on device tensors (ids / labels int64 [B, L]): no host round trip, so the FiLM forward
+        can be captured in a hipGraph.  Returned padded to a multiple of 8 rows (GEMM M granularity of the FiLM Linears)."""
+        B = ids_dev.shape[0]
+        avg = torch.zeros(((B + 7) // 8 * 8, self.cfg.llm_dim), dtype=BF16, device=self.device)
+        return ops.language_average(ids_dev, lab_dev, self.embed, avg)
 
     def forward(self, input_ids, attention_mask, pixel_values, labels, proprio=None, noisy_actions=None, timestep_emb=None, train=False,
                 proprio_projector=None, noisy_action_projector=None, cached_patches=None, sel=None):
@@ -917,12 +912,9 @@ class VLAEngine:
         ids = input_ids.to(dev, torch.int64).contiguous()
         lab = labels.to(dev, torch.int64).contiguous()
         lens = self.check_right_padding(attention_mask)
-        film_avg = None
-        if self.use_film and cached_patches is None:
-            film_avg = self.language_average(ids, labels.to("cpu"))
         return self.forward_dev(ids, lab, lens.to(torch.int32).to(dev), pixel_values, proprio=proprio, noisy_actions=noisy_actions,
                                 timestep_emb=timestep_emb, train=train, proprio_projector=proprio_projector,
-                                noisy_action_projector=noisy_action_projector, cached_patches=cached_patches, film_avg=film_avg, sel=sel)
+                                noisy_action_projector=noisy_action_projector, cached_patches=cached_patches, sel=sel)
 
     @staticmethod
     def check_right_padding(attention_mask) -> torch.Tensor:
@@ -947,6 +939,8 @@ class VLAEngine:
         if cached_patches is not None:
             base, n_vis = cached_patches
         else:
+            if self.use_film and film_avg is None:
+                film_avg = self.language_average(ids, lab)
             patches, vsaved = self.vision_fwd(pixel_values.to(dev, BF16).contiguous(), train, film_avg)
             n_vis = patches.shape[1]
             base = patches
@@ -981,10 +975,13 @@ class VLAEngine:
                 sel_rows = None          # (e.g. ALOHA discrete: 4 x 351 rows) -> the full last layer
         hidden, lsaved = self.llm.fwd(mm.view(B * S, cfg.llm_dim), B, S, kv_len, train, sel=sel_rows)
         saved = (vsaved, psaved, nsaved, lsaved, B, S, P, n_vis, proprio_projector, noisy_action_projector, action_rows) if train else None
+        # `all_patches` [B, P, D]: what sits between BOS and the text in the multimodal sequence (projected patches + proprio + timestep
+        # tokens) = the reference's `projector_features` (modeling_prismatic.py:586-599, 674)
         if sel_rows is not None:
-            return dict(hidden=None, action_hidden=hidden, sel_rows=sel_rows, P=P, S=S, action_rows=action_rows, patches=(base, n_vis), saved=saved)
+            return dict(hidden=None, action_hidden=hidden, sel_rows=sel_rows, P=P, S=S, action_rows=action_rows, patches=(base, n_vis), saved=saved,
+                        all_patches=allp)
         return dict(hidden=hidden.view(B, S, cfg.llm_dim), action_hidden=None, sel_rows=None, P=P, S=S, action_rows=action_rows, patches=(base, n_vis),
-                    saved=saved)
+                    saved=saved, all_patches=allp)
 
     def action_hidden(self, out):
         """(hidden rows that predict the action slots [B*A, D], their flattened row indices) of a forward() result, whether the last
@@ -1151,8 +1148,6 @@ class ChunkGraph:
     padding is masked exactly: padded keys contribute exact zeros) or keep one ChunkGraph per L."""
 
     def __init__(self, engine: "VLAEngine", B: int, L: int, pixel_shape, *, head=None, use_proprio: bool = True, proprio_projector=None):
-        if engine.use_film:
-            raise NotImplementedError("ChunkGraph: the FiLM language average is computed host-side; use the eager forward")
         dev = engine.device
         self.engine, self.head, self.B, self.L = engine, head, B, L
         self.proprio_projector = proprio_projector

@@ -11,7 +11,6 @@ glue (`loss = L1Loss(gt, head.predict_action(h)); loss.backward()`) works unchan
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass
 from typing import Any, Dict, Optional, Tuple
 
 import os
@@ -244,15 +243,82 @@ class NoisyActionProjector(ProprioProjector):
 # ======================================================================================================================
 # the VLA
 # ======================================================================================================================
-@dataclass
+class _LMLossFn(torch.autograd.Function):
+    """`output.loss` of the reference's forward (LlamaForCausalLM with `labels`: logits.float(), shift by one, cross entropy with
+    ignore_index -100, mean over the counted labels; modeling_prismatic.py:632-643 + :486-496 for the multimodal labels), computed on
+    the counted rows only: frozen lm_head GEMM on the gathered hidden rows, `ovla_token_ce` (fp32 log-sum-exp, gradient written in place),
+    and in the backward one GEMM with the transposed lm_head + a row scatter into d hidden."""
+
+    @staticmethod
+    def forward(ctx, hidden, vla, labels, P):
+        eng = vla.engine
+        if eng.lm_head is None:
+            raise RuntimeError("output.loss / output.logits need language_model.lm_head.weight, which this checkpoint was loaded without")
+        B, S, D = hidden.shape
+        lab = labels.to("cpu", torch.int64)
+        bb, jj = torch.nonzero(lab[:, 1:] != IGNORE_INDEX, as_tuple=True)
+        n_tok = int(bb.numel())
+        if n_tok == 0:
+            raise ValueError("no label in the batch is different from IGNORE_INDEX")
+        # text position j + 1 is predicted by the hidden state of text position j, which is multimodal row P + j (BOS is row 0)
+        rows_idx = (bb * S + P + jj).to(torch.int32).to(eng.device)
+        targets = lab[bb, jj + 1].contiguous().to(eng.device)
+        n_pad = (n_tok + 7) // 8 * 8
+        x = torch.zeros((n_pad, D), dtype=BF16, device=eng.device)
+        ops.gather_rows(hidden.detach().reshape(B * S, D), rows_idx, D, dst=x)
+        logits = ops.gemm(x, eng.lm_head)
+        need_grad = ctx.needs_input_grad[0]
+        loss_rows, amax, _ = ops.token_ce(logits[:n_tok], targets, grad_scale=(1.0 / n_tok) if need_grad else None)
+        if need_grad:
+            if n_pad > n_tok:
+                logits[n_tok:].zero_()
+            ctx.dlogits, ctx.rows_idx, ctx.shape, ctx.eng = logits, rows_idx, (B, S, D), eng
+        vla._last_token_argmax = (bb, jj, amax)
+        return loss_rows.sum() / n_tok
+
+    @staticmethod
+    def backward(ctx, dloss):
+        eng = ctx.eng
+        B, S, D = ctx.shape
+        if getattr(eng, "_lm_head_t", None) is None:
+            eng._lm_head_t = ops.transpose(eng.lm_head)
+        dx = ops.gemm(ctx.dlogits, eng._lm_head_t, alpha=float(dloss))
+        dhidden = torch.zeros((B * S, D), dtype=BF16, device=eng.device)
+        ops.gather_rows(dx, ctx.rows_idx, D, dst=dhidden, scatter_add=True)
+        return dhidden.view(B, S, D), None, None, None
+
+
 class PrismaticCausalLMOutputWithPast:
-    """prismatic/extern/hf/modeling_prismatic.py:266-278"""
-    loss: Optional[torch.Tensor] = None
-    logits: Optional[torch.Tensor] = None
-    past_key_values: Any = None
-    hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
-    attentions: Any = None
-    projector_features: Optional[torch.Tensor] = None
+    """prismatic/extern/hf/modeling_prismatic.py:266-278 / :668-675.  `hidden_states[-1]` (post final norm) and `projector_features`
+    are materialised by the forward; `loss` and `logits` -- which the reference always computes and the L1 / diffusion recipes throw
+    away (finetune.py:396-407) -- are computed on first access: `loss` as an autograd node on the hidden state (`loss.backward()`
+    works), `logits` as the fp32 [B, S, vocab] tensor of the frozen lm_head without a gradient edge (0.6 GB at B = 8)."""
+
+    past_key_values = None
+    attentions = None
+
+    def __init__(self, vla, hidden, labels, P, projector_features):
+        self._vla, self._labels, self._P = vla, labels, P
+        self.hidden_states = (hidden,)
+        self.projector_features = projector_features
+        self._loss = self._logits = None
+
+    @property
+    def loss(self) -> torch.Tensor:
+        if self._loss is None:
+            self._loss = _LMLossFn.apply(self.hidden_states[-1], self._vla, self._labels, self._P)
+        return self._loss
+
+    @property
+    def logits(self) -> torch.Tensor:
+        if self._logits is None:
+            h = self.hidden_states[-1].detach()
+            B, S, D = h.shape
+            self._logits = self._vla.logits_for(h.reshape(B * S, D)).view(B, S, -1)
+        return self._logits
+
+    def __getitem__(self, key):   # ModelOutput-style access: out["loss"], out["hidden_states"]
+        return getattr(self, key)
 
 
 class _VisionBackboneHandle:
@@ -368,9 +434,9 @@ class OpenVLAForActionPrediction(_StoreModule):
         else:
             with torch.no_grad():
                 hidden, _ = _VLMFn.apply(self._anchor, self, kwargs, False)
-        # the reference also returns the CE loss / fp32 logits of the frozen lm_head; in L1 / diffusion mode they are
-        # discarded (finetune.py:400,407), so they are produced lazily only for the discrete path (see `logits_for`)
-        return PrismaticCausalLMOutputWithPast(loss=None, logits=None, hidden_states=(hidden,), projector_features=None)
+        # the reference also returns the CE loss / fp32 logits of the frozen lm_head; in L1 / diffusion mode they are discarded
+        # (finetune.py:400,407), so the output object computes them on first access only
+        return PrismaticCausalLMOutputWithPast(self, hidden, labels, self._last["P"], self._last["all_patches"])
 
     def logits_for(self, hidden_rows: torch.Tensor) -> torch.Tensor:
         """lm_head on selected hidden rows [n, D] -> fp32 logits [n, vocab] (discrete action-token path, :929-942)."""
@@ -424,7 +490,7 @@ class OpenVLAForActionPrediction(_StoreModule):
                 cur = sched.step(eps, int(t), cur).prev_sample.to(BF16).float()
             normalized = cur.reshape(cfg.chunk, cfg.action_dim).numpy()
             return self._unnormalize_actions(normalized, unnorm_key), ah.view(1, A, cfg.llm_dim)
-        if self.use_graph and not self.engine.use_film:
+        if self.use_graph:
             # one hipGraph per (text length, head, projector): ~1.3 k launches -> one graph launch (engine.ChunkGraph)
             head_comp = getattr(action_head, "comp", None) if action_head is not None else None
             pp_comp = proprio_projector.comp if use_proprio else None

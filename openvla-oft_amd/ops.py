@@ -416,6 +416,18 @@ def masked_mean(x, row_mask, B, L, dim):
     return out
 
 
+def language_average(ids, labels, table, out, *, action_token_begin=31743):
+    """out[:B] = mean of table[ids] over the non-action text positions (ovla.h: ovla_language_average); ids / labels int64 [B, L] on the device."""
+    B, L = ids.shape
+    assert ids.dtype == torch.int64 and labels.dtype == torch.int64 and ids.is_contiguous() and labels.is_contiguous() and ids.is_cuda and labels.is_cuda
+    assert out.shape[0] >= B and out.shape[1] == table.shape[1] and out.is_contiguous()
+    g = STRUCTS["ovla_language_average_args"]()
+    g.ids, g.labels, g.embed_table, g.out = ids.data_ptr(), labels.data_ptr(), table.data_ptr(), out.data_ptr()
+    g.B, g.L, g.D, g.vocab, g.action_token_begin = B, L, table.shape[1], table.shape[0], action_token_begin
+    _lib.call("ovla_language_average", g, _stream())
+    return out
+
+
 def image_prep(images_u8, *, crop: bool, crop_scale: float = 0.9, out_size: int = 224,
                mean=(0.485, 0.456, 0.406, 0.5, 0.5, 0.5), std=(0.229, 0.224, 0.225, 0.5, 0.5, 0.5)):
     """uint8 [n_img, H, W, 3] (device) -> bf16 [1, 6 * n_img, out, out] pixel_values: center crop (TF crop_and_resize rule) +

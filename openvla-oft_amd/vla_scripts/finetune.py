@@ -107,14 +107,41 @@ def learning_rate_at(cfg, gradient_step_idx: int) -> float:
     return lr
 
 
+def run_diffusion_sampling(vla, action_head, noisy_action_projector, proprio_projector, batch, batch_size, num_patches, actions_shape, device_id,
+                           current_action_mask, next_actions_mask, use_proprio, use_film) -> torch.Tensor:
+    """finetune.py:454-540: reverse diffusion for the whole batch -- start from N(0, 1) noise, and for every DDIM timestep predict the
+    noise from the action rows of the VLM's last hidden state and step x_t -> x_{t-1}.  The reference re-runs the vision backbone in every
+    step; its output does not depend on t, so here the projected patches of the first step are reused (same numbers, one tower pass)."""
+    head, eng = action_head.module, vla.module.engine
+    cfg = eng.cfg
+    A = cfg.num_action_tokens
+    cur = torch.randn((batch_size, C.NUM_ACTIONS_CHUNK, C.ACTION_DIM)).to(torch.bfloat16)
+    head.noise_scheduler.set_timesteps(head.num_diffusion_steps)
+    cached = None
+    for t in head.noise_scheduler.timesteps:
+        temb = head.time_encoder(torch.full((batch_size,), float(t))).to(torch.bfloat16).unsqueeze(1)          # (B, 1, llm_dim)
+        out = eng.forward(batch["input_ids"], batch["attention_mask"], batch["pixel_values"], batch["labels"],
+                          proprio=batch["proprio"] if use_proprio else None, train=False, noisy_actions=cur, timestep_emb=temb,
+                          proprio_projector=proprio_projector.module.comp if use_proprio else None,
+                          noisy_action_projector=noisy_action_projector.module.comp, cached_patches=cached, sel="actions")
+        cached = out["patches"]
+        ah, _ = eng.action_hidden(out)
+        noise_pred = head.predict_noise(ah.view(batch_size, A, cfg.llm_dim)).reshape(cur.shape).float().cpu()
+        cur = head.noise_scheduler.step(noise_pred, t, cur.float()).prev_sample.to(torch.bfloat16)
+    return cur.reshape(actions_shape).to(device_id)
+
+
 def run_forward_pass(vla, action_head, noisy_action_projector, proprio_projector, batch, action_tokenizer, device_id, use_l1_regression,
                      use_diffusion, use_proprio, use_film, num_patches, compute_diffusion_l1=False, num_diffusion_steps=None
                      ) -> Tuple[torch.Tensor, Dict[str, float]]:
-    """finetune.py:280-451 with the reference's signature, L1-regression branch, through the autograd bridge of
-    modeling.py (`loss.backward()` then drives the engine's explicit backward)."""
-    if not (use_l1_regression or use_diffusion):
-        raise NotImplementedError("the discrete next-token objective is not part of the OFT recipes built here")
-    metrics = {}
+    """finetune.py:280-451 with the reference's signature and all three objectives, through the autograd bridge of modeling.py
+    (`loss.backward()` then drives the engine's explicit backward):
+      discrete (neither head flag)   loss = output.loss (next-token cross entropy), token accuracies and decoded L1 of the current /
+                                     next actions from output.logits[:, num_patches:-1].argmax(2)                       (:357-378)
+      use_l1_regression              L1Loss(gt, head.predict_action(action rows))                                       (:396-400)
+      use_diffusion                  MSE(noise_pred, noise); with compute_diffusion_l1 additionally a full DDIM sampling
+                                     (run_diffusion_sampling) for the current / next L1 metrics                         (:402-430)"""
+    metrics: Dict[str, float] = {}
     gt = batch["actions"].to(device_id).to(torch.bfloat16)
     noisy = None
     if use_diffusion:                                                                   # :327-333
@@ -127,20 +154,35 @@ def run_forward_pass(vla, action_head, noisy_action_projector, proprio_projector
                  diffusion_timestep_embeddings=noisy["diffusion_timestep_embeddings"] if use_diffusion else None)
     ids = batch["labels"][:, 1:].to(device_id)
     cur, nxt = get_current_action_mask(ids), get_next_actions_mask(ids)
+    if not (use_l1_regression or use_diffusion):                                        # :357-378
+        from ..prismatic.training.train_utils import compute_actions_l1_loss, compute_token_accuracy
+
+        loss = output.loss
+        predicted = output.logits[:, num_patches:-1].argmax(dim=2)
+        metrics["loss_value"] = loss.item()
+        for name, m in (("curr_action", cur), ("next_actions", nxt)):
+            metrics[f"{name}_accuracy"] = compute_token_accuracy(predicted, ids, mask=m).item()
+            metrics[f"{name}_l1_loss"] = compute_actions_l1_loss(action_tokenizer, predicted, ids, mask=m).item()
+        return loss, metrics
     last = output.hidden_states[-1]
     text_hidden = last[:, num_patches:-1]
     B = batch["input_ids"].shape[0]
     ah = text_hidden[cur | nxt].reshape(B, C.NUM_ACTIONS_CHUNK * C.ACTION_DIM, -1).to(torch.bfloat16)
-    if use_diffusion:                                                                   # :402-407
+    pred = None
+    if use_l1_regression:
+        pred = action_head.module.predict_action(ah)
+        loss = torch.nn.L1Loss()(gt, pred)
+    if use_diffusion:                                                                   # :402-430
         noise_pred = action_head.module.predict_noise(ah).reshape(noisy["noise"].shape)
         loss = torch.nn.functional.mse_loss(noise_pred, noisy["noise"].to(noise_pred.device), reduction="mean")
-        metrics["loss_value"] = loss.item()
-        return loss, metrics
-    pred = action_head.module.predict_action(ah)
-    loss = torch.nn.L1Loss()(gt, pred)
+        if compute_diffusion_l1:
+            with torch.no_grad():
+                pred = run_diffusion_sampling(vla, action_head, noisy_action_projector, proprio_projector, batch, B, num_patches, gt.shape, device_id,
+                                              cur, nxt, use_proprio, use_film)
     metrics["loss_value"] = loss.item()
-    metrics["curr_action_l1_loss"] = torch.nn.L1Loss()(gt[:, 0], pred[:, 0]).item()
-    metrics["next_actions_l1_loss"] = torch.nn.L1Loss()(gt[:, 1:], pred[:, 1:]).item()
+    if pred is not None:                                                                # :437-448 (should_log_l1_loss)
+        metrics["curr_action_l1_loss"] = torch.nn.L1Loss()(gt[:, 0], pred[:, 0]).item()
+        metrics["next_actions_l1_loss"] = torch.nn.L1Loss()(gt[:, 1:], pred[:, 1:]).item()
     return loss, metrics
 
 

@@ -1,10 +1,14 @@
 """Timing-only ablations of gemm_nt (results are wrong by construction): where do the main loop's cycles go?
 tile + 1000: no global->LDS traffic after the first two K tiles; tile + 2000: every K tile re-reads LDS buffer 0 only;
 tile + 4000: every workgroup stages tile (0, 0) (global loads always hit L2)."""
-import importlib, sys
+import importlib, os, subprocess, sys
 from pathlib import Path
 import torch
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+# the ablation branches exist only in the -DOVLA_GEMM_ABLATE build (csrc/build.sh ablate); the product library rejects tile >= 1000
+subprocess.run(["bash", str(ROOT / "openvla-oft_amd" / "csrc" / "build.sh"), "ablate"], check=True)
+os.environ["OVLA_LIB_NAME"] = "libovla_hip_ablate.so"
 ops = importlib.import_module("openvla-oft_amd.ops")
 dev = torch.device("cuda:0")
 def bench(fn, iters=20):
