@@ -2,24 +2,35 @@
 # Builds libovla_hip.so (gfx950 only) in-tree next to the sources.  hipcc cross-compiles without a GPU.
 #   build.sh          the product library
 #   build.sh ablate   libovla_hip_ablate.so: the same sources with -DOVLA_GEMM_ABLATE (timing ablations of gemm_nt, tools/gemm_ablate.py)
-# Staleness is decided by CONTENT, not mtime: the sha256 of every source / header / this script is compiled into the library
-# (ovla_build_hash()) and written next to it; _lib.py refuses to load a library whose hash differs from the sources it sits beside.
+#   build.sh packed   libovla_hip_packed.so: WITH the compiler's packed-FP32 VALU instructions (A/B measurement only)
+#
+# Packed FP32 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_mov_b32, which clang emits on gfx950 whenever two fp32 operations pair up) is switched
+# OFF for every file of the product library.  Root cause recorded in DESIGN.md "Run-to-run determinism" (tools/norm_bwd_wave_probe.py):
+# a wave-per-row LayerNorm backward built with it dropped exactly one term of a per-lane running sum in lanes 48-63 of a few waves per
+# launch whenever another stream's kernels shared the CUs -- operands bit-identical (hashes of every loaded dword), the good run equal to a
+# host recomputation; the same source without packed FP32 never failed (3948 / 3368 differing rows vs 0 / 0, alternated), one stream never
+# failed.  Measured cost of switching it off everywhere: none (170.4 / 170.1 vs 170.7 / 170.2 ms/step, alternated).
 set -euo pipefail
 cd "$(dirname "$0")"
 MODE="${1:-product}"
 OUT=../libovla_hip.so; EXTRA=""; BUILD=../_build
+NOPK="core.hip gemm_nt.hip gemm_tn.hip attention.hip elementwise.hip head_optim.hip selftest.hip"
 if [ "$MODE" = "ablate" ]; then OUT=../libovla_hip_ablate.so; EXTRA="-DOVLA_GEMM_ABLATE"; BUILD=../_build_ablate; fi
+if [ "$MODE" = "packed" ]; then OUT=../libovla_hip_packed.so; BUILD=../_build_packed; NOPK=""; fi
+NOPK_FLAGS="-Xclang -target-feature -Xclang -packed-fp32-ops"   # (the host pass prints "not a recognized feature ... ignoring": filtered below)
 SRCS="core.hip gemm_nt.hip gemm_tn.hip attention.hip elementwise.hip head_optim.hip selftest.hip"
 HASH=$(cat $(ls *.hip *.h | LC_ALL=C sort) build.sh ../../include/ovla.h | sha256sum | cut -c1-32)
-if [ -f "$OUT" ] && [ -f "$OUT.hash" ] && [ "$(cat "$OUT.hash")" = "$HASH" ]; then echo "$(basename $OUT) up to date ($HASH)"; exit 0; fi
+STAMP="$HASH-$MODE"
+if [ -f "$OUT" ] && [ -f "$OUT.hash" ] && [ "$(cat "$OUT.hash")" = "$STAMP" ]; then echo "$(basename $OUT) up to date ($HASH)"; exit 0; fi
 mkdir -p $BUILD
 pids=()
 for s in $SRCS; do
-  hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result $EXTRA -DOVLA_SRC_HASH="\"$HASH\"" -c "$s" -o "$BUILD/${s%.hip}.o" &
+  F=""; case " $NOPK " in *" $s "*) F="$NOPK_FLAGS";; esac
+  hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result $EXTRA $F -DOVLA_SRC_HASH="\"$HASH\"" -c "$s" -o "$BUILD/${s%.hip}.o" 2> >(grep -v "is not a recognized feature for this target" >&2) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
 objs=""; for s in $SRCS; do objs="$objs $BUILD/${s%.hip}.o"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" $objs
-echo "$HASH" > "$OUT.hash"
+echo "$STAMP" > "$OUT.hash"
 echo "built $(realpath $OUT) ($HASH)"
