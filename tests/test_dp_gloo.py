@@ -26,13 +26,13 @@ class _Store:
         self.flat_grad = {torch.bfloat16: torch.randn(1000, generator=g), torch.float32: torch.randn(333, generator=g)}
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, comm_dtype="fp32"):
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dp = importlib.import_module("openvla-oft_amd.dp")
     stores = [_Store(rank), _Store(rank + 10)]
-    red = dp.GradReducer(stores, world, bucket_bytes=1024)      # force several buckets per buffer
+    red = dp.GradReducer(stores, world, bucket_bytes=1024, comm_dtype=comm_dtype)      # force several buckets per buffer
     assert len(list(red.buckets())) > 8
     # overlapped protocol: frontiers arrive during the "backward", the tail goes out in all_reduce(); every element must
     # be reduced exactly once
@@ -54,6 +54,19 @@ def test_grad_reducer_world2(tmp_path):
         expect = {str(k): _Store(0 + base).flat_grad[k] + _Store(1 + base).flat_grad[k] for k in (torch.bfloat16, torch.float32)}
         for k, v in expect.items():
             assert torch.allclose(r0[si][k], v) and torch.equal(r0[si][k], r1[si][k]), k
+
+
+def test_grad_reducer_world2_parameter_dtype_on_the_wire(tmp_path):
+    """comm_dtype="param" (default; DDP's behaviour, finetune.py:224): the accumulators of bf16 parameters cross the wire as bf16
+    (each rank's gradient rounded once, summed in bf16), fp32 parameters stay fp32."""
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), "param"), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in (0, 1))
+    for si, base in enumerate((0, 10)):
+        a, b = _Store(0 + base).flat_grad, _Store(1 + base).flat_grad
+        want16 = (a[torch.bfloat16].to(torch.bfloat16) + b[torch.bfloat16].to(torch.bfloat16)).float()
+        assert torch.equal(r0[si][str(torch.bfloat16)], want16) and torch.equal(r1[si][str(torch.bfloat16)], want16)
+        assert torch.allclose(r0[si][str(torch.float32)], a[torch.float32] + b[torch.float32])
 
 
 def test_single_rank_is_a_no_op():
