@@ -261,7 +261,7 @@ class DDIM:
 def sinusoidal_encoding(t: torch.Tensor, dim: int) -> torch.Tensor:
     """prismatic/models/action_heads.py:26-35"""
     half = dim // 2
-    exponent = torch.arange(half) * -math.log(10000) / (half - 1)
+    exponent = torch.arange(half, device=t.device) * -math.log(10000) / (half - 1)
     emb = t[:, None] * torch.exp(exponent)[None, :]
     return torch.cat((emb.sin(), emb.cos()), dim=-1)
 
@@ -465,10 +465,12 @@ class Oracle:
             pf = self.mlp_projector(self.R(proprio.reshape(patches.shape[0], -1).to(patches.dtype)), "proprio_projector.")
             patches = torch.cat((patches, pf[:, None, :]), dim=1)
         if timestep_emb is not None:                                                    # :594-599
-            patches = torch.cat((patches, self.R(timestep_emb)), dim=1)
+            patches = torch.cat((patches, self.R(timestep_emb).to(patches.dtype)), dim=1)
         if noisy_actions is not None:                                                   # :602-616
             B = noisy_actions.shape[0]
-            feats = self.mlp_projector(self.R(noisy_actions.reshape(B, -1, 1).float()), "noisy_action_projector.")
+            na = noisy_actions.reshape(B, -1, 1)
+            na = na.to(patches.dtype) if self.mode == "native" else self.R(na.float())     # autocast runs the projector's Linears in bf16
+            feats = self.mlp_projector(na, "noisy_action_projector.")
             emb = emb.clone()
             for b in range(B):
                 emb[b, amask[b]] = feats[b]

@@ -153,3 +153,95 @@ def test_full_size_gradients_against_autograd(full, dev):
     # ReLU gates of the head and GELU / SiLU slopes flip between ANY two evaluations that differ by bf16 noise: the yardstick is the
     # eager path's own agreement with fp32 autograd
     assert min(cos.values()) >= min(cos_nat.values()) - 0.02
+
+
+def test_full_size_config5_film_diffusion_step(dev):
+    """BASELINE.json configs[4] shapes on one GPU at FULL size (recipe ALOHA.md:59-84): 3 images, 25 x 14 action chunk, proprio 14, FiLM
+    + diffusion head, batch 4, S = 1159 -- one fine-tune step (fwd + bwd + AdamW), noise-prediction MSE loss checked against the oracle in
+    fp32 and in its native (stock PyTorch-ROCm eager bf16) mode on the same seeded weights, noise and timesteps; then the same step again
+    from the updated weights (the loss must move, every gradient finite).  The 8-GPU leg of configs[4] cannot run here (one GPU)."""
+    import dataclasses
+
+    load = importlib.import_module
+    engine_mod, weights_mod, synth, config_mod, dmod = (load("openvla-oft_amd.engine"), load("openvla-oft_amd.weights"), load("openvla-oft_amd.synthetic"),
+                                                        load("openvla-oft_amd.config"), load("openvla-oft_amd.diffusion"))
+    cfg = dataclasses.replace(config_mod.OPENVLA_7B, num_images=3, chunk=25, action_dim=14, proprio_dim=14, norm_type="bounds")
+    sd = weights_mod.random_state_dict(cfg, dev, seed=0, lm_head=False, film=True, diffusion=True)
+    get, has = weights_mod.make_getter(sd, dev)
+    eng = engine_mod.VLAEngine(cfg, get, dev, lora=True, use_proprio=True, head="diffusion", use_film=True, has=has)
+    Bsz = 4
+    batch = synth.make_batch(Bsz, seed=1000, num_images=3, chunk=25, action_dim=14, proprio_dim=14)
+    S = 1 + 3 * cfg.dino.n_patches + 2 + (batch["input_ids"].shape[1] - 1)
+    assert S == 1159 and batch["input_ids"].shape[1] == 38 + 350 + 1
+    g = torch.Generator().manual_seed(4)
+    noise = torch.randn(Bsz, 25, 14, generator=g).to(BF).float()
+    timesteps = torch.tensor([3, 41, 17, 28])
+    sched, enc = dmod.DDIMScheduler(50), dmod.SinusoidalPositionalEncoding(cfg.llm_dim)
+    diffusion = dict(noise=noise, noisy_actions=sched.add_noise(batch["actions"].to(BF).float(), noise, timesteps).to(BF), timestep_emb=enc(timesteps.float()).to(BF))
+
+    ocfg = sh.oracle_config(cfg)
+    ref = {}
+    for mode in ("fp32", "native"):
+        fdt = BF if mode == "native" else torch.float32
+        o = sh.vo.Oracle(ocfg, sd, mode=mode)
+        b = sh.device_batch(batch, dev, fdt)
+        ddim = sh.vo.DDIM(50)
+        ddim.alphas_cumprod = ddim.alphas_cumprod.to(dev)
+        with torch.no_grad():
+            loss, pred, _ = o.train_forward(b, use_diffusion=True, use_film=True, noise=noise.to(dev, fdt), timesteps=timesteps.to(dev), ddim=ddim)
+        ref[mode] = (loss.item(), pred.float())
+    eng.zero_grad()
+    loss_sum, count, pred = eng.train_step_fwd_bwd(batch, diffusion=diffusion)
+    torch.cuda.synchronize()
+    loss = loss_sum.item() / count
+    assert count == Bsz * 25 * 14
+    e_hip = (pred.float().view(Bsz, 25, 14) - ref["fp32"][1]).abs().max().item()
+    e_nat = (ref["native"][1] - ref["fp32"][1]).abs().max().item()
+    print(f"\nconfig 5 full size: MSE loss hip {loss:.5f} native {ref['native'][0]:.5f} fp32 {ref['fp32'][0]:.5f}; noise prediction L-inf hip-fp32 {e_hip:.3e} "
+          f"native-fp32 {e_nat:.3e}; HBM {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    _dump("config5_full.json", {"loss": [loss, ref["native"][0], ref["fp32"][0]], "pred_linf": [e_hip, e_nat]})
+    assert abs(loss - ref["fp32"][0]) <= max(3 * abs(ref["native"][0] - ref["fp32"][0]), 1.5e-2 * abs(ref["fp32"][0]))
+    assert e_hip <= 1.5 * e_nat + 2 * 2.0 ** -7
+    grads = eng.export_trainable("grad")
+    assert all(torch.isfinite(v).all() for v in grads.values())
+    film = [k for k in grads if ".scale.weight" in k or ".shift.weight" in k]
+    assert len(film) == 2 * (23 + 26) and all(grads[k].abs().max() > 0 for k in film), "every executed block's FiLM pair gets a gradient (the discarded last block has none)"
+    assert any(k.startswith("noisy_action_projector.") for k in grads)
+    # every gradient tensor (LoRA of both towers / projector / decoder, the 98 fp32 FiLM Linears, proprio + noisy-action projectors, the
+    # diffusion head) against torch.autograd through the oracle in fp32; yardstick = autograd through the native eager bf16 path
+    names = sorted(grads)
+    g_hip = {k: grads[k].float().clone() for k in names}
+
+    def autograd(mode):
+        fdt = BF if mode == "native" else torch.float32
+        sdg = dict(sd)
+        for k in names:
+            sdg[k] = sd[k].detach().to(fdt).clone().requires_grad_(True)
+        ddim = sh.vo.DDIM(50)
+        ddim.alphas_cumprod = ddim.alphas_cumprod.to(dev)
+        l, _, _ = sh.vo.Oracle(ocfg, sdg, mode=mode).train_forward(sh.device_batch(batch, dev, fdt), use_diffusion=True, use_film=True,
+                                                                  noise=noise.to(dev, fdt), timesteps=timesteps.to(dev), ddim=ddim)
+        l.backward()
+        return {k: (sdg[k].grad.float() if sdg[k].grad is not None else torch.zeros_like(sdg[k], dtype=torch.float32)) for k in names}
+
+    g32 = autograd("fp32")
+    gc.collect(); torch.cuda.empty_cache()
+    gn = autograd("native")
+    gc.collect(); torch.cuda.empty_cache()
+    fam = {}
+    for k in names:
+        if g32[k].norm() < 1e-12:
+            assert g_hip[k].norm() < 1e-6, k
+            continue
+        f = "film" if (".scale." in k or ".shift." in k) else ("lora" if ".lora_" in k else k.split(".")[0])
+        fam.setdefault(f, []).append((sh.rel2(g_hip[k], g32[k]), sh.rel2(gn[k], g32[k]), k))
+    rep = {f: (float(np.median([e[0] for e in v])), float(np.median([e[1] for e in v])), max(v)[0], max(v, key=lambda e: e[1])[1], len(v)) for f, v in fam.items()}
+    for f, r in rep.items():
+        print(f"config 5 gradients [{f}] n={r[4]}: rel-L2 vs fp32 autograd median hip {r[0]:.4f} native {r[1]:.4f}; max hip {r[2]:.4f} native {r[3]:.4f}")
+    _dump("config5_grads.json", rep)
+    for f, r in rep.items():
+        assert r[0] <= 1.25 * r[1] + 5e-3, f"{f}: median gradient error {r[0]:.4f} vs the eager path's {r[1]:.4f}"
+        assert r[2] <= 1.5 * r[3] + 3e-2, f"{f}: worst gradient error {r[2]:.4f} vs the eager path's {r[3]:.4f}"
+    del eng, sd
+    gc.collect()
+    torch.cuda.empty_cache()
