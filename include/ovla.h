@@ -243,8 +243,8 @@ int ovla_image_prep(const ovla_image_prep_args* a, void* stream);
  * dlimp's `resize_image` (rlds/obs_transforms.py:83) call): rows first into an fp32 intermediate [n, out_h, W, 3], then columns;
  * out = sum_k weights[o, k] * in[starts[o] + k] accumulated in span order from 0, each multiply and add rounded on its own; then
  * tf.round (half to even), clip to [0, 255], uint8.  The spans (starts int32 [out], weights fp32 [out, span]) are computed by the host
- * (image_prep.lanczos3_spans) and passed as device arrays.  The reference's JPEG encode/decode round trip before the resize is NOT
- * reproduced (libjpeg's lossy codec); PARITY UNPINNED against TensorFlow, bit-compared with oracle/data_oracle.py. */
+ * (image_prep.lanczos3_spans) and passed as device arrays.  The reference's JPEG encode/decode round trip before the resize is
+ * ovla_jpeg_roundtrip below; PARITY UNPINNED against TensorFlow, bit-compared with oracle/data_oracle.py. */
 typedef struct {
   const void* src; void* dst; void* workspace; int64_t workspace_bytes;
   const int32_t* row_starts; const float* row_weights; const int32_t* col_starts; const float* col_weights;
@@ -252,6 +252,16 @@ typedef struct {
 } ovla_image_resize_args;
 int64_t ovla_image_resize_workspace_bytes(int32_t n_img, int32_t W, int32_t out_h);
 int ovla_image_resize(const ovla_image_resize_args* a, void* stream);
+
+/* The JPEG encode -> decode round trip of `resize_image_for_policy` (experiments/robot/openvla_utils.py:532-533: tf.image.encode_jpeg(img)
+ * then tf.io.decode_image(...), default arguments = libjpeg-turbo baseline 4:2:0 at quality 95, accurate integer DCT, fancy upsampling) as
+ * two launches, without the (lossless) entropy coder: per 16 x 16 MCU RGB -> YCbCr, 2x2 chroma box filter, 8x8 forward DCT, quantise,
+ * dequantise, inverse DCT -> component planes in `workspace`; then triangle-filter chroma upsampling + YCbCr -> RGB per pixel.  Integer
+ * arithmetic throughout, bit-identical to oracle/jpeg_oracle.py, which is pinned to libjpeg-turbo's own output (tests/golden/g12).
+ * src / dst uint8 [n_img, H, W, 3] (any H, W >= 1: edges are padded by replication as the library does); quality 1..100. */
+typedef struct { const void* src; void* dst; void* workspace; int64_t workspace_bytes; int32_t n_img, H, W, quality; } ovla_jpeg_roundtrip_args;
+int64_t ovla_jpeg_roundtrip_workspace_bytes(int32_t n_img, int32_t H, int32_t W);
+int ovla_jpeg_roundtrip(const ovla_jpeg_roundtrip_args* a, void* stream);
 
 /* Training-time image path as two launches (replaces the TF/dlimp frame transform + PIL/torchvision processor of the reference's data
  * loader: prismatic/vla/datasets/rlds/obs_transforms.py:18-45 `augment` -> dlimp `augment_image` with the kwargs of

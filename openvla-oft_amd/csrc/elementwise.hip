@@ -930,6 +930,202 @@ extern "C" int ovla_image_resize(const ovla_image_resize_args* a, void* stream_)
   return OVLA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// JPEG encode -> decode round trip (ovla.h: ovla_jpeg_roundtrip).  libjpeg-turbo's arithmetic, restated: jccolor.c / jcsample.c /
+// jfdctint.c / jcdctmgr.c / jidctint.c / jdsample.c / jdcolor.c (published algorithms; the library is not in the reference tree).
+namespace {
+struct JpegParams {
+  const uint8_t* src; uint8_t* dst; uint8_t* planes;     // planes: Y [n, H16, W16] | Cb [n, H16/2, W16/2] | Cr [n, H16/2, W16/2]
+  int n_img, H, W, H16, W16;
+  int16_t ql[64], qc[64];                                 // quantisation tables, natural order
+};
+constexpr int J_CONST_BITS = 13, J_PASS1_BITS = 2;
+constexpr int JF_0_298631336 = 2446, JF_0_390180644 = 3196, JF_0_541196100 = 4433, JF_0_765366865 = 6270, JF_0_899976223 = 7373, JF_1_175875602 = 9633,
+              JF_1_501321110 = 12299, JF_1_847759065 = 15137, JF_1_961570560 = 16069, JF_2_053119869 = 16819, JF_2_562915447 = 20995, JF_3_072711026 = 25172;
+OVLA_DEV int jdescale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+constexpr int jfix(double x) { return (int)(x * 65536.0 + 0.5); }
+
+OVLA_DEV void jpeg_ycc(const uint8_t* px, int& y, int& cb, int& cr) {       // jccolor.c rgb_ycc_convert
+  const int r = px[0], g = px[1], b = px[2];
+  y = (jfix(0.29900) * r + jfix(0.58700) * g + jfix(0.11400) * b + 32768) >> 16;
+  cb = (-jfix(0.16874) * r - jfix(0.33126) * g + jfix(0.50000) * b + (128 << 16) + 32767) >> 16;
+  cr = (jfix(0.50000) * r - jfix(0.41869) * g - jfix(0.08131) * b + (128 << 16) + 32767) >> 16;
+}
+
+// one 1-D pass of jfdctint.c over 8 values with stride `st`
+OVLA_DEV void jpeg_fdct8(int* d, int st, bool first) {
+  const int d0 = d[0], d1 = d[st], d2 = d[2 * st], d3 = d[3 * st], d4 = d[4 * st], d5 = d[5 * st], d6 = d[6 * st], d7 = d[7 * st];
+  const int tmp0 = d0 + d7, tmp7 = d0 - d7, tmp1 = d1 + d6, tmp6 = d1 - d6, tmp2 = d2 + d5, tmp5 = d2 - d5, tmp3 = d3 + d4, tmp4 = d3 - d4;
+  const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  const int sh = first ? J_CONST_BITS - J_PASS1_BITS : J_CONST_BITS + J_PASS1_BITS;
+  d[0] = first ? (tmp10 + tmp11) << J_PASS1_BITS : jdescale(tmp10 + tmp11, J_PASS1_BITS);
+  d[4 * st] = first ? (tmp10 - tmp11) << J_PASS1_BITS : jdescale(tmp10 - tmp11, J_PASS1_BITS);
+  int z1 = (tmp12 + tmp13) * JF_0_541196100;
+  d[2 * st] = jdescale(z1 + tmp13 * JF_0_765366865, sh);
+  d[6 * st] = jdescale(z1 + tmp12 * (-JF_1_847759065), sh);
+  z1 = tmp4 + tmp7;
+  int z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
+  const int z5 = (z3 + z4) * JF_1_175875602;
+  const int t4 = tmp4 * JF_0_298631336, t5 = tmp5 * JF_2_053119869, t6 = tmp6 * JF_3_072711026, t7 = tmp7 * JF_1_501321110;
+  z1 *= -JF_0_899976223; z2 *= -JF_2_562915447; z3 = z3 * (-JF_1_961570560) + z5; z4 = z4 * (-JF_0_390180644) + z5;
+  d[7 * st] = jdescale(t4 + z1 + z3, sh);
+  d[5 * st] = jdescale(t5 + z2 + z4, sh);
+  d[3 * st] = jdescale(t6 + z2 + z3, sh);
+  d[st] = jdescale(t7 + z1 + z4, sh);
+}
+
+// one 1-D pass of jidctint.c
+OVLA_DEV void jpeg_idct8(int* d, int st, bool first) {
+  const int i0 = d[0], i1 = d[st], i2 = d[2 * st], i3 = d[3 * st], i4 = d[4 * st], i5 = d[5 * st], i6 = d[6 * st], i7 = d[7 * st];
+  int z1 = (i2 + i6) * JF_0_541196100;
+  const int tmp2 = z1 + i6 * (-JF_1_847759065), tmp3 = z1 + i2 * JF_0_765366865;
+  const int tmp0 = (i0 + i4) << J_CONST_BITS, tmp1 = (i0 - i4) << J_CONST_BITS;
+  const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  int t0 = i7, t1 = i5, t2 = i3, t3 = i1;
+  z1 = t0 + t3;
+  int z2 = t1 + t2, z3 = t0 + t2, z4 = t1 + t3;
+  const int z5 = (z3 + z4) * JF_1_175875602;
+  t0 *= JF_0_298631336; t1 *= JF_2_053119869; t2 *= JF_3_072711026; t3 *= JF_1_501321110;
+  z1 *= -JF_0_899976223; z2 *= -JF_2_562915447; z3 = z3 * (-JF_1_961570560) + z5; z4 = z4 * (-JF_0_390180644) + z5;
+  t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+  const int sh = first ? J_CONST_BITS - J_PASS1_BITS : J_CONST_BITS + J_PASS1_BITS + 3;
+  d[0] = jdescale(tmp10 + t3, sh); d[7 * st] = jdescale(tmp10 - t3, sh);
+  d[st] = jdescale(tmp11 + t2, sh); d[6 * st] = jdescale(tmp11 - t2, sh);
+  d[2 * st] = jdescale(tmp12 + t1, sh); d[5 * st] = jdescale(tmp12 - t1, sh);
+  d[3 * st] = jdescale(tmp13 + t0, sh); d[4 * st] = jdescale(tmp13 - t0, sh);
+}
+
+OVLA_DEV int jpeg_range_limit(int x) {          // sample_range_limit + CENTERJSAMPLE indexed with x & RANGE_MASK
+  const int m = x & 1023;
+  return m < 128 ? m + 128 : (m < 512 ? 255 : (m < 896 ? 0 : m - 896));
+}
+
+// One workgroup per MCU (16 x 16 pixels = 4 Y blocks + 1 Cb + 1 Cr block of 8 x 8).
+__global__ __launch_bounds__(256) void jpeg_codec_kernel(const JpegParams p) {
+  __shared__ int ws[6][64];
+  const int tid = threadIdx.x, img = blockIdx.z;
+  const int y0 = blockIdx.y * 16, x0 = blockIdx.x * 16;
+  const uint8_t* src = p.src + (int64_t)img * p.H * p.W * 3;
+  {   // luma: thread (ty, tx) of the MCU; edges replicate the last column / row (expand_right_edge / expand_bottom_edge)
+    const int ty = tid >> 4, tx = tid & 15;
+    const int gy = min(y0 + ty, p.H - 1), gx = min(x0 + tx, p.W - 1);
+    int y, cb, cr;
+    jpeg_ycc(src + ((int64_t)gy * p.W + gx) * 3, y, cb, cr);
+    ws[(ty >> 3) * 2 + (tx >> 3)][(ty & 7) * 8 + (tx & 7)] = y - 128;
+  }
+  if (tid < 64) {   // chroma: h2v2_downsample; the input is widened by column replication and made even-height by row replication, rows of the
+                    // last iMCU row beyond the real data replicate the last DOWNSAMPLED row
+    const int cy = tid >> 3, cx = tid & 7;
+    const int hc = (p.H + 1) >> 1;
+    const int rc = min(blockIdx.y * 8 + cy, hc - 1), c = blockIdx.x * 8 + cx;
+    const int r0 = 2 * rc, r1 = min(2 * rc + 1, p.H - 1), c0 = min(2 * c, p.W - 1), c1 = min(2 * c + 1, p.W - 1);
+    int sb = 0, sr = 0, y, cb, cr;
+    jpeg_ycc(src + ((int64_t)r0 * p.W + c0) * 3, y, cb, cr); sb += cb; sr += cr;
+    jpeg_ycc(src + ((int64_t)r0 * p.W + c1) * 3, y, cb, cr); sb += cb; sr += cr;
+    jpeg_ycc(src + ((int64_t)r1 * p.W + c0) * 3, y, cb, cr); sb += cb; sr += cr;
+    jpeg_ycc(src + ((int64_t)r1 * p.W + c1) * 3, y, cb, cr); sb += cb; sr += cr;
+    const int bias = (c & 1) ? 2 : 1;                 // alternating 1, 2 along the output row (the MCU starts at an even column)
+    ws[4][cy * 8 + cx] = ((sb + bias) >> 2) - 128;
+    ws[5][cy * 8 + cx] = ((sr + bias) >> 2) - 128;
+  }
+  __syncthreads();
+  const int blk = tid >> 3, k = tid & 7;              // 48 (block, row / column) tasks
+  if (tid < 48) jpeg_fdct8(&ws[blk][k * 8], 1, true);                 // FDCT pass 1: rows
+  __syncthreads();
+  if (tid < 48) {                                                     // FDCT pass 2 on column k, quantise, dequantise, IDCT pass 1 on the same column
+    int* col = &ws[blk][k];
+    jpeg_fdct8(col, 8, false);
+    const int16_t* q = blk < 4 ? p.ql : p.qc;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int v = col[r * 8], qv = q[r * 8 + k], div = qv << 3;
+      const int a = v < 0 ? -v : v;
+      const int quant = (a + (div >> 1)) / div;
+      col[r * 8] = (v < 0 ? -quant : quant) * qv;
+    }
+    jpeg_idct8(col, 8, true);
+  }
+  __syncthreads();
+  if (tid < 48) jpeg_idct8(&ws[blk][k * 8], 1, false);                // IDCT pass 2: rows (still scaled; range-limited at the store)
+  __syncthreads();
+  {
+    const int ty = tid >> 4, tx = tid & 15;
+    uint8_t* Y = p.planes + (int64_t)img * p.H16 * p.W16;
+    Y[(int64_t)(y0 + ty) * p.W16 + x0 + tx] = (uint8_t)jpeg_range_limit(ws[(ty >> 3) * 2 + (tx >> 3)][(ty & 7) * 8 + (tx & 7)]);
+  }
+  if (tid < 128) {
+    const int comp = tid >> 6, cy = (tid >> 3) & 7, cx = tid & 7;
+    const int hc16 = p.H16 >> 1, wc16 = p.W16 >> 1;
+    uint8_t* C = p.planes + (int64_t)p.n_img * p.H16 * p.W16 + ((int64_t)comp * p.n_img + img) * hc16 * wc16;
+    C[(int64_t)(blockIdx.y * 8 + cy) * wc16 + blockIdx.x * 8 + cx] = (uint8_t)jpeg_range_limit(ws[4 + comp][cy * 8 + cx]);
+  }
+}
+
+// jdsample.c h2v2_fancy_upsample at one output position of the REAL chroma plane [hc, wc] (row stride ld)
+OVLA_DEV int jpeg_fancy(const uint8_t* C, int ld, int hc, int wc, int y, int x) {
+  const int r = y >> 1, c = x >> 1;
+  const int rn = (y & 1) ? min(r + 1, hc - 1) : max(r - 1, 0);
+  const int cur = 3 * C[r * ld + c] + C[rn * ld + c];
+  if (x & 1) {
+    if (c == wc - 1) return (cur * 4 + 7) >> 4;
+    return (cur * 3 + 3 * C[r * ld + c + 1] + C[rn * ld + c + 1] + 7) >> 4;
+  }
+  if (c == 0) return (cur * 4 + 8) >> 4;
+  return (cur * 3 + 3 * C[r * ld + c - 1] + C[rn * ld + c - 1] + 8) >> 4;
+}
+
+__global__ __launch_bounds__(256) void jpeg_upsample_color_kernel(const JpegParams p) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per = (int64_t)p.H * p.W;
+  if (idx >= per * p.n_img) return;
+  const int img = (int)(idx / per), y = (int)((idx % per) / p.W), x = (int)(idx % p.W);
+  const int hc16 = p.H16 >> 1, wc16 = p.W16 >> 1, hc = (p.H + 1) >> 1, wc = (p.W + 1) >> 1;
+  const uint8_t* Y = p.planes + (int64_t)img * p.H16 * p.W16;
+  const uint8_t* Cb = p.planes + (int64_t)p.n_img * p.H16 * p.W16 + (int64_t)img * hc16 * wc16;
+  const uint8_t* Cr = Cb + (int64_t)p.n_img * hc16 * wc16;
+  const int yy = Y[(int64_t)y * p.W16 + x];
+  const int xb = jpeg_fancy(Cb, wc16, hc, wc, y, x) - 128, xr = jpeg_fancy(Cr, wc16, hc, wc, y, x) - 128;
+  const int r = yy + ((jfix(1.40200) * xr + 32768) >> 16);                                   // jdcolor.c ycc_rgb_convert
+  const int g = yy + ((-jfix(0.34414) * xb + 32768 - jfix(0.71414) * xr) >> 16);
+  const int b = yy + ((jfix(1.77200) * xb + 32768) >> 16);
+  uint8_t* o = p.dst + idx * 3;
+  o[0] = (uint8_t)min(max(r, 0), 255); o[1] = (uint8_t)min(max(g, 0), 255); o[2] = (uint8_t)min(max(b, 0), 255);
+}
+}  // namespace
+
+extern "C" int64_t ovla_jpeg_roundtrip_workspace_bytes(int32_t n_img, int32_t H, int32_t W) {
+  if (n_img <= 0 || H <= 0 || W <= 0) return 0;
+  const int64_t H16 = (H + 15) / 16 * 16, W16 = (W + 15) / 16 * 16;
+  return (int64_t)n_img * (H16 * W16 + 2 * (H16 / 2) * (W16 / 2));
+}
+
+extern "C" int ovla_jpeg_roundtrip(const ovla_jpeg_roundtrip_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->src && a->dst && a->workspace, "ovla_jpeg_roundtrip: null pointer");
+  OVLA_REQUIRE(a->n_img > 0 && a->H > 0 && a->W > 0 && a->H <= 16384 && a->W <= 16384, "ovla_jpeg_roundtrip: bad shape %d x %d x %d", a->n_img, a->H, a->W);
+  OVLA_REQUIRE(a->quality >= 1 && a->quality <= 100, "ovla_jpeg_roundtrip: quality %d outside 1..100", a->quality);
+  OVLA_REQUIRE(a->workspace_bytes >= ovla_jpeg_roundtrip_workspace_bytes(a->n_img, a->H, a->W), "ovla_jpeg_roundtrip: needs a workspace of %lld bytes",
+               (long long)ovla_jpeg_roundtrip_workspace_bytes(a->n_img, a->H, a->W));
+  static const int kLuma[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                                18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+  static const int kChroma[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                                  99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+  JpegParams p;
+  p.src = (const uint8_t*)a->src; p.dst = (uint8_t*)a->dst; p.planes = (uint8_t*)a->workspace;
+  p.n_img = a->n_img; p.H = a->H; p.W = a->W; p.H16 = (a->H + 15) / 16 * 16; p.W16 = (a->W + 15) / 16 * 16;
+  const int scale = a->quality < 50 ? 5000 / a->quality : 200 - 2 * a->quality;     // jpeg_quality_scaling; jpeg_add_quant_table(force_baseline)
+  for (int i = 0; i < 64; ++i) {
+    int l = (kLuma[i] * scale + 50) / 100, c = (kChroma[i] * scale + 50) / 100;
+    p.ql[i] = (int16_t)(l < 1 ? 1 : (l > 255 ? 255 : l));
+    p.qc[i] = (int16_t)(c < 1 ? 1 : (c > 255 ? 255 : c));
+  }
+  hipLaunchKernelGGL(jpeg_codec_kernel, dim3(p.W16 / 16, p.H16 / 16, p.n_img), dim3(256), 0, stream, p);
+  OVLA_CHECK_LAUNCH("ovla_jpeg_roundtrip(codec)");
+  hipLaunchKernelGGL(jpeg_upsample_color_kernel, dim3((unsigned)(((int64_t)p.n_img * p.H * p.W + 255) / 256)), dim3(256), 0, stream, p);   // one thread per pixel, not grid-stride
+  OVLA_CHECK_LAUNCH("ovla_jpeg_roundtrip(upsample)");
+  return OVLA_OK;
+}
+
 extern "C" int64_t ovla_image_augment_workspace_bytes(int32_t n_img, int32_t out) {
   if (n_img <= 0 || out <= 0) return 0;
   const int64_t tmp = (((int64_t)n_img * out * out * 3 * 4) + 15) / 16 * 16;

@@ -146,15 +146,16 @@ prepare_images_for_vla = image_prep.prepare_images_for_vla
 def device_pixel_values(images: List[np.ndarray], cfg: Any) -> torch.Tensor:
     """prepare_images_for_vla + processor(...)["pixel_values"] of every image, concatenated on dim 1, computed on the device: the
     uint8 frames go to HBM as they are (150 KB each); center crop, uint8 re-quantisation and both backbones' normalisations are ONE
-    kernel (ovla_image_prep), bit-identical to image_prep.center_crop_image + apply_transform; frames of another size are first
-    resized on the device like the reference's resize_image_for_policy minus its JPEG round trip.  -> bf16 [1, 6 * n, 224, 224]."""
+    kernel (ovla_image_prep), bit-identical to image_prep.center_crop_image + apply_transform; frames of another size first go through the
+    reference's resize_image_for_policy on the device (ovla_jpeg_roundtrip, then ovla_image_resize).  -> bf16 [1, 6 * n, 224, 224]."""
     side = image_prep.OPENVLA_IMAGE_SIZE
     for image in images:
         image_prep.check_image_format(image)
     if any(image.shape != images[0].shape for image in images):
         images = [image if image.shape == (side, side, 3) else image_prep.resize_image_for_policy(image, side, device=DEVICE) for image in images]
     frames = torch.from_numpy(np.ascontiguousarray(np.stack(images))).to(DEVICE, non_blocking=True)
-    if frames.shape[1:3] != (side, side):      # lanczos3 + antialias resize of all frames in one pair of launches (ovla_image_resize)
+    if frames.shape[1:3] != (side, side):      # JPEG round trip + lanczos3 antialias resize of all frames, two launches each
+        frames = ops.jpeg_roundtrip(frames)
         spans = [tuple(torch.from_numpy(a).to(DEVICE) for a in image_prep.lanczos3_spans(n, side)) for n in frames.shape[1:3]]
         frames = ops.image_resize(frames, spans[0], spans[1])
     return ops.image_prep(frames, crop=bool(cfg.center_crop))

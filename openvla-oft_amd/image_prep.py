@@ -1,6 +1,6 @@
 """Host-side image preparation of the inference glue, without TensorFlow / torchvision.
 
-  resize_image_for_policy  experiments/robot/openvla_utils.py:516-540  (lanczos3 + antialias resize on the device; no JPEG round trip)
+  resize_image_for_policy  experiments/robot/openvla_utils.py:516-540  (JPEG encode/decode round trip, then lanczos3 + antialias resize: both on the device)
   center_crop_image        experiments/robot/openvla_utils.py:542-622  (tf.image.crop_and_resize of the central
                            sqrt(0.9) x sqrt(0.9) box back to 224 x 224, bilinear, on float [0,1], back to uint8)
   apply_transform          prismatic/extern/hf/processing_prismatic.py:128-145 (per-backbone to_tensor + normalise, channel
@@ -101,10 +101,11 @@ def lanczos3_spans(in_size: int, out_size: int):
     return _SPAN_CACHE[key]
 
 
-def resize_image_for_policy(img: np.ndarray, resize_size, device=None) -> np.ndarray:
-    """experiments/robot/openvla_utils.py:516-540 without its JPEG encode/decode round trip (libjpeg's lossy codec is not
-    restatable here): tf.image.resize(lanczos3, antialias=True) -> round -> clip -> uint8, on the device
-    (ovla_image_resize).  img uint8 [H, W, 3] -> uint8 [h, w, 3]."""
+def resize_image_for_policy(img: np.ndarray, resize_size, device=None, jpeg: bool = True) -> np.ndarray:
+    """experiments/robot/openvla_utils.py:516-540: tf.image.encode_jpeg -> tf.io.decode_image (ovla_jpeg_roundtrip: libjpeg-turbo's baseline
+    4:2:0 quality-95 codec without the entropy coder, bit-identical to the library), then tf.image.resize(lanczos3, antialias=True) ->
+    round -> clip -> uint8 (ovla_image_resize), all on the device.  img uint8 [H, W, 3] -> uint8 [h, w, 3].  `jpeg=False` skips the codec (the
+    training collator's resize of stored frames, rlds/obs_transforms.py:83, has none)."""
     import importlib
 
     ops = importlib.import_module(__package__ + ".ops")      # the HIP library: required
@@ -113,13 +114,16 @@ def resize_image_for_policy(img: np.ndarray, resize_size, device=None) -> np.nda
     check_image_format(img)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     spans = [tuple(torch.from_numpy(a).to(dev) for a in lanczos3_spans(n_in, n_out)) for n_in, n_out in ((img.shape[0], oh), (img.shape[1], ow))]
-    out = ops.image_resize(torch.from_numpy(np.ascontiguousarray(img))[None].to(dev), spans[0], spans[1])
+    frames = torch.from_numpy(np.ascontiguousarray(img))[None].to(dev)
+    if jpeg:
+        frames = ops.jpeg_roundtrip(frames)
+    out = ops.image_resize(frames, spans[0], spans[1])
     return out[0].cpu().numpy()
 
 
 def prepare_images_for_vla(images, cfg):
-    """experiments/robot/openvla_utils.py:678-708: frames that are not 224 x 224 are resized like the training pipeline's
-    (lanczos3, antialias; the reference's JPEG round trip before it is not reproduced), then center-cropped if configured."""
+    """experiments/robot/openvla_utils.py:678-708: frames that are not 224 x 224 go through resize_image_for_policy (JPEG round trip +
+    lanczos3 antialias resize), then the center crop if configured."""
     out = []
     for image in images:
         check_image_format(image)

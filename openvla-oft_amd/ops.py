@@ -466,6 +466,21 @@ def image_resize(images_u8, row_spans, col_spans):
     return out
 
 
+def jpeg_roundtrip(images_u8, quality: int = 95):
+    """uint8 [n, H, W, 3] (device) -> the same frames after a baseline 4:2:0 JPEG encode + decode at `quality` (ovla.h: ovla_jpeg_roundtrip;
+    tf.image.encode_jpeg + tf.io.decode_image of experiments/robot/openvla_utils.py:532-533)."""
+    assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3 and images_u8.is_contiguous() and images_u8.is_cuda
+    n, H, W, _ = images_u8.shape
+    out = torch.empty_like(images_u8)
+    wsb = int(_lib.lib().ovla_jpeg_roundtrip_workspace_bytes(n, H, W))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=images_u8.device)
+    g = STRUCTS["ovla_jpeg_roundtrip_args"]()
+    g.src, g.dst, g.workspace, g.workspace_bytes = images_u8.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb
+    g.n_img, g.H, g.W, g.quality = n, H, W, int(quality)
+    _lib.call("ovla_jpeg_roundtrip", g, _stream())
+    return out
+
+
 AUG_CROP, AUG_BRIGHTNESS, AUG_CONTRAST, AUG_SATURATION, AUG_HUE = 1, 2, 4, 8, 16
 AUG_ALL = 31
 

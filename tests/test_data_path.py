@@ -349,3 +349,37 @@ def test_prepare_images_accepts_simulator_frames(ops, dev):
     want = torch.cat([ip.apply_transform(h) for h in host])[None].to(BF)
     assert torch.equal(pv.cpu(), want)
     assert np.array_equal(ip.resize_image_for_policy(frames[1], (112, 200)), do.resize_lanczos3(frames[1], 112, 200))
+
+
+@pytest.mark.gpu
+def test_jpeg_roundtrip_kernel_is_bit_identical_to_libjpeg_turbo(dev):
+    """ovla_jpeg_roundtrip (two launches: per-MCU colour conversion / chroma box filter / FDCT / quantise / dequantise / IDCT, then fancy
+    upsampling + colour conversion) against libjpeg-turbo's own outputs (G12) and, at the sizes the policies see (256 x 256 LIBERO frames,
+    480 x 640 ALOHA frames, a batch of 3), against the oracle that is pinned to them."""
+    import importlib
+
+    from oracle import jpeg_oracle as jo
+
+    ops = importlib.import_module("openvla-oft_amd.ops")
+    g = np.load(Path(__file__).resolve().parent / "golden" / "g12_jpeg_roundtrip.npz")
+    for name in sorted(k[:-4] for k in g.files if k.endswith("__in")):
+        img = torch.from_numpy(g[name + "__in"])[None].to(dev)
+        for q in (95, 50, 100):
+            if f"{name}__q{q}" in g.files:
+                got = ops.jpeg_roundtrip(img, quality=q)[0].cpu().numpy()
+                assert np.array_equal(got, g[f"{name}__q{q}"]), f"{name} q{q}: {int((got != g[f'{name}__q{q}']).sum())} bytes differ from libjpeg-turbo"
+    rng = np.random.default_rng(5)
+    for shape in ((3, 256, 256, 3), (2, 480, 640, 3), (1, 250, 243, 3)):
+        smooth = np.clip(rng.normal(128, 50, (shape[0], shape[1] // 8 + 1, shape[2] // 8 + 1, 3)).repeat(8, 1).repeat(8, 2)[:, : shape[1], : shape[2]]
+                         + rng.normal(0, 5, shape), 0, 255).astype(np.uint8)
+        got = ops.jpeg_roundtrip(torch.from_numpy(smooth).to(dev)).cpu().numpy()
+        want = np.stack([jo.jpeg_roundtrip(f) for f in smooth])
+        assert np.array_equal(got, want), f"{shape}: {int((got != want).sum())} bytes differ"
+        assert 0 < np.abs(got.astype(int) - smooth.astype(int)).max() < 64, "a lossy codec at quality 95: close to, not equal to, the input"
+    # resize_image_for_policy = round trip + lanczos3 antialias resize (the eval loops' 256 -> 224 path)
+    ip = importlib.import_module("openvla-oft_amd.image_prep")
+    frame = smooth[0]
+    a, b = ip.resize_image_for_policy(frame, 224), ip.resize_image_for_policy(frame, 224, jpeg=False)
+    assert a.shape == (224, 224, 3) and a.dtype == np.uint8 and not np.array_equal(a, b)
+    with pytest.raises(Exception, match="quality"):
+        ops.jpeg_roundtrip(torch.from_numpy(frame)[None].to(dev), quality=0)

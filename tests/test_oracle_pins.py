@@ -199,3 +199,25 @@ def test_g11_config1_plumbing_regression():
     actions, _ = vo.Oracle(ocfg, sd).predict_action(ids, torch.ones_like(ids, dtype=torch.bool), pv[:, :, ::4, ::4].contiguous(), proprio=prop,
                                                     unnorm_stats={"q01": [-1.0] * 7, "q99": [1.0] * 7, "mask": [True] * 6 + [False]})
     assert np.asarray(actions).shape == (8, 7) and np.allclose(actions, g["actions"], atol=1e-5)
+
+
+def test_jpeg_roundtrip_oracle_reproduces_libjpeg_turbo():
+    """G12: the JPEG encode -> decode round trip of resize_image_for_policy (experiments/robot/openvla_utils.py:532-533).  The fixtures are
+    libjpeg-turbo's own outputs (tests/golden/make_golden_jpeg.py, through Pillow); the integer restatement in oracle/jpeg_oracle.py must
+    reproduce every byte -- odd sizes (edge replication), saturated blocks (range limiting) and three quality settings included."""
+    import numpy as np
+
+    from oracle import jpeg_oracle as jo
+
+    g = np.load(G / "g12_jpeg_roundtrip.npz")
+    cases = sorted(k[:-4] for k in g.files if k.endswith("__in"))
+    assert len(cases) == 7
+    for name in cases:
+        img = g[name + "__in"]
+        for q in (95, 50, 100):
+            key = f"{name}__q{q}"
+            if key in g.files:
+                got = jo.jpeg_roundtrip(img, quality=q)
+                assert got.dtype == np.uint8 and np.array_equal(got, g[key]), f"{key}: {int((got != g[key]).sum())} bytes differ from libjpeg-turbo"
+    ql, qc = jo.quant_tables(95)
+    assert ql[0] == 2 and qc[0] == 2 and ql[63] == 10 and int(ql.min()) == 1
