@@ -303,7 +303,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   // the next tile's first fragment reads, so the matrix pipe has work while those reads (and the LDS-DMA issue) are in
   // flight instead of every wave draining its pipeline at each barrier.
   constexpr int BPR = (NT + MT - 1) / MT;  // next-substep B fragments fetched per row
-  const int arow = wm * WTM + (lane & 15), brow = wn * WTN + (lane & 15), cq = lane >> 4;
+  // Column map of the wave's NT accumulator tiles.  Plain: tile j = columns wn*WTN + 16 j.  RoPE tiles of the 2x4 layout (the q | k
+  // heads of the fused q|k|v projection, head_dim 128 = two 64-column wave strips): wave (h = wn >> 1, w2 = wn & 1) takes columns
+  // h*128 + 32 w2 + [0, 32) AND their rotation partners h*128 + 64 + 32 w2 + [0, 32), i.e. tile j sits at 16 (j & 1) + 64 (j >> 1): the
+  // partner of tile j is tile j ^ 2 of the SAME wave, 32 floats away in the same row of its own epilogue slab -- the rotation needs no
+  // other wave's data and no extra barrier, and 8 consecutive slab columns are still 8 consecutive output columns (16-byte stores).
+  bool rope_tile = false;
+  if constexpr (WN == 4 && WTN == 64 && BN == 256) rope_tile = p.rope_cos != nullptr && n0 < p.rope_cols;
+  int bcol[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bcol[j] = rope_tile ? ((wn >> 1) * 128 + (wn & 1) * 32 + (j & 1) * 16 + (j >> 1) * 64) : (wn * WTN + j * 16);
+  const int arow = wm * WTM + (lane & 15), brl = lane & 15, cq = lane >> 4;
   bf16x8_bits b0[NT], b1[NT];
   bf16x8_bits a_def = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     };
     constexpr int NP0 = PP < PPS ? PP : PPS;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) b0[j] = lds_frag(sB, brow + j * 16, cq);
+    for (int j = 0; j < NT; ++j) b0[j] = lds_frag(sB, bcol[j] + brl, cq);
     bf16x8_bits a_cur = lds_frag(sA, arow, cq);
     if constexpr (SPREAD) pieces(std::integral_constant<int, 0>{});
     __builtin_amdgcn_s_setprio(1);
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
       if constexpr (sub == 0) {
 #pragma unroll
         for (int jj = 0; jj < BPR; ++jj)
-          if (i * BPR + jj < NT) b1[i * BPR + jj] = lds_frag(sB, brow + (i * BPR + jj) * 16, 4 + cq);
+          if (i * BPR + jj < NT) b1[i * BPR + jj] = lds_frag(sB, bcol[i * BPR + jj] + brl, 4 + cq);
       }
       constexpr int NPR = (r + 1 < MT) ? (((r + 2) * PPS <= PP) ? PPS : (((r + 1) * PPS < PP) ? PP - (r + 1) * PPS : 0)) : 0;
       if constexpr (SPREAD && NPR > 0) pieces(std::integral_constant<int, r + 1>{});
@@ -405,7 +415,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        *reinterpret_cast<f32x4*>(slab + (wm * WTM + i * 16 + (lane & 15)) * BN + wn * WTN + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+        *reinterpret_cast<f32x4*>(slab + (wm * WTM + i * 16 + (lane & 15)) * BN + bcol[j] + 4 * (lane >> 4)) = acc[i][j];
     return;
   }
   if (p.split_k > 1) {  // raw fp32 partials; the reduce kernel applies the epilogue
@@ -435,6 +445,46 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   // 11-17 % of a 256x256 tile's time and 44 % of a ViT fc1 launch: bias + GELU + pre-activation save.)
   // (the 256x256 configs hold 128 accumulator registers: unrolling the activation code there spills, and no 256x256-tiled GEMM of
   // this model has an activation -- those keep the alpha / bias / residual subset)
+  if constexpr (WN == 4 && WTN == 64 && BN == 256) {
+    if (rope_tile) {   // RoPE in the unrolled read-back (host guarantees an interior tile, alpha only, 16-byte aligned tables)
+      constexpr int STEPS = RM * 16 * 8 / 64;
+      const int mbase = m0 + wm * WTM, nhead = n0 + (wn >> 1) * 128, chalf = (wn & 1) * 32;
+      __syncthreads();
+#pragma unroll
+      for (int round = 0; round < MT / RM; ++round) {
+#pragma unroll
+        for (int ii = 0; ii < RM; ++ii)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            *reinterpret_cast<f32x4*>(wstage + (ii * 16 + (lane & 15)) * LDSW + j * 16 + 4 * (lane >> 4)) = acc[round * RM + ii][j];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+          const int idx = st * 64 + lane, row = idx >> 3, c8 = idx & 7;
+          const float* xs = wstage + row * LDSW + c8 * 8;
+          const float* ys = wstage + row * LDSW + (c8 ^ 4) * 8;          // rotation partner: slab column +- 32 = output column +- 64
+          const f32x4 xlo = *reinterpret_cast<const f32x4*>(xs), xhi = *reinterpret_cast<const f32x4*>(xs + 4);
+          const f32x4 ylo = *reinterpret_cast<const f32x4*>(ys), yhi = *reinterpret_cast<const f32x4*>(ys + 4);
+          const int cin = chalf + ((c8 & 3) << 3);                         // column within the 64-wide half of the head
+          const bool upper = c8 >= 4;
+          const int m = mbase + round * RM * 16 + row, n = nhead + cin + (upper ? 64 : 0);
+          const int pos = m % p.rope_S;
+          const bf16x8_bits cs = *reinterpret_cast<const bf16x8_bits*>(p.rope_cos + (int64_t)pos * 64 + cin);
+          const bf16x8_bits sn = *reinterpret_cast<const bf16x8_bits*>(p.rope_sin + (int64_t)pos * 64 + cin);
+          bf16x8_bits o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {    // rope_kernel's arithmetic on y = bf16(acc): lo' = bf16(a c) + bf16(-b s), hi' = bf16(b c) + bf16(a s)
+            const float x = bfround((e < 4 ? xlo[e] : xhi[e - 4]) * p.alpha), y = bfround((e < 4 ? ylo[e] : yhi[e - 4]) * p.alpha);
+            const float cc = bf2f((bf16_bits)cs[e]), sv = bf2f((bf16_bits)sn[e]);
+            o[e] = (short)f2bf(upper ? bfround(x * cc) + bfround(y * sv) : bfround(x * cc) + bfround(-y * sv));
+          }
+          *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      return;
+    }
+  }
   constexpr bool FAST_ACT = MT * NT <= 16;
   if (p.fast_epi && (FAST_ACT || (p.act == OVLA_ACT_NONE && !p.Cpre && !p.colscale)) && !OVLA_DBG(64) && m0 + BM <= p.M && n0 + BN <= p.N &&
       (WTN % 8) == 0) {
@@ -1094,6 +1144,7 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   OVLA_REQUIRE(a->tile < 1000, "ovla_gemm_bf16: tile %d selects a timing ablation; this library was built without OVLA_GEMM_ABLATE", a->tile);
   p.dbg = 0;
 #endif
+  const bool rope_plain = !a->bias && !a->C_pre && !a->colscale && !a->residual && !a->film_gamma && !a->dact_src && a->act == OVLA_ACT_NONE;
   p.fast_epi = !a->film_gamma && !a->dact_src && !a->rope_cos && (!a->C_pre || (((uintptr_t)a->C_pre) & 15) == 0) &&
                (!a->colscale || (((uintptr_t)a->colscale) & 15) == 0) &&
                (!a->residual || ((((uintptr_t)a->residual) & 15) == 0 && (a->ldr % 8) == 0)) && (!a->bias || (((uintptr_t)a->bias) & 15) == 0);
@@ -1130,7 +1181,11 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   if (a->rope_cos) {
     // fused only where one wave slab is one head (256x256 tile, 4x2 waves) and the epilogue runs in-kernel or in the hybrid reduce;
     // every other schedule computes the plain projection and rotates it with one ovla_rope launch (same arithmetic)
-    const bool fused = (tile == 16 || tile == 116) && p.split_k <= 1;
+    // ... or, on the default 2x4 layout, where every q | k tile is an interior tile whose waves take the columns together with their
+    // rotation partners (gemm_nt_kernel: rope_tile): M, N and rope_cols multiples of 256, nothing but alpha in the epilogue
+    const bool fused17 = (tile == 17 || tile == 117) && p.split_k <= 1 && rope_plain && (p.M % 256) == 0 && (p.N % 256) == 0 && (a->rope_cols % 256) == 0 &&
+                         (((uintptr_t)a->rope_cos | (uintptr_t)a->rope_sin | (uintptr_t)a->C) & 15) == 0 && (a->ldc % 8) == 0;
+    const bool fused = ((tile == 16 || tile == 116) && p.split_k <= 1) || fused17;
     if (fused) {
       p.rope_cos = (const bf16_bits*)a->rope_cos; p.rope_sin = (const bf16_bits*)a->rope_sin;
     } else {

@@ -32,10 +32,12 @@ F32 = torch.float32
 # (B = 8: none 177.1-177.6 ms/step, act 177.5-178.0, swiglu 178.0, all 178.1-178.4): a 256x256 tile owns its CU, so the extra epilogue
 # traffic is exposed, while the separate elementwise kernels already run at the HBM roofline.  Default: separate kernels.
 _FUSE = os.environ.get("OVLA_FUSE_DACT", "none")
-# Same story for the forward RoPE in the q|k|v projection's epilogue (bit-identical, 176.7-177.0 ms/step without vs 177.8-178.0 with:
-# two table loads + a partner LDS read per quad inside an exposed epilogue cost more than the 33 us HBM-roofline pass they replace).
+# The forward RoPE rides in the q|k|v projection's epilogue (bit-identical to the separate rope pass).  Round 1 had it only in the 4x2-wave
+# layout's ROLLED epilogue, where it cost more than the 33 us pass it replaced (177.8-178.0 vs 176.7-177.0 ms/step) and was left off; round 2
+# put it into the default 2x4 layout's unrolled read-back (a wave takes its columns together with their rotation partners: no extra LDS
+# traffic beyond one more slab read, no barrier) -- see DESIGN.md section 6 for the A/B.  OVLA_FUSE_ROPE_FWD=0 restores the separate pass.
 # The INVERSE RoPE of the backward, which needs no loads beyond the tables and no LDS (attention-backward epilogue), is on: -0.6 ms.
-_FUSE_ROPE_FWD = os.environ.get("OVLA_FUSE_ROPE_FWD", "0") == "1"
+_FUSE_ROPE_FWD = os.environ.get("OVLA_FUSE_ROPE_FWD", "1") == "1"
 _FUSE_ACT, _FUSE_SWIGLU = _FUSE in ("act", "all"), _FUSE in ("swiglu", "all")
 
 

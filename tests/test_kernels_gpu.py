@@ -579,10 +579,12 @@ def test_attn_bwd_fused_inverse_rope(ops, dev, hd, S, causal):
     assert torch.equal(d_fused, d_ref)
 
 
-@pytest.mark.parametrize("M,S,tile", [(4864, 608, 0), (4864, 608, 116), (4864, 608, 117), (608, 608, 0), (1216, 304, 16), (700, 100, 1), (520, 130, 2)])
+@pytest.mark.parametrize("M,S,tile", [(4864, 608, 0), (4864, 608, 116), (4864, 608, 117), (4864, 608, 17), (512, 128, 17), (608, 608, 0), (608, 608, 17),
+                                      (1216, 304, 16), (700, 100, 1), (520, 130, 2)])
 def test_gemm_rope_epilogue(ops, dev, M, S, tile):
-    """RoPE in the q|k|v projection's epilogue (fused in the 256x256 config incl. its hybrid-remainder reduce; other schedules append
-    one ovla_rope launch) == plain GEMM followed by the separate RoPE pass, bit for bit.  3 heads of 128: q | k rotated, v untouched."""
+    """RoPE in the q|k|v projection's epilogue (fused in the 256x256 configs: 2x4 waves = the default layout, in its unrolled read-back with
+    the partner-column wave map, and 4x2 waves; both incl. the hybrid-remainder reduce; other schedules and non-multiple-of-256 M append one
+    ovla_rope launch) == plain GEMM followed by the separate RoPE pass, bit for bit.  2 q | 2 k | 2 v heads of 128: q | k rotated, v untouched."""
     torch.manual_seed(M + tile)
     hd, K = 128, 512
     N = 3 * 2 * hd                      # 2 q heads | 2 k heads | 2 v heads
