@@ -379,6 +379,34 @@ typedef struct {
 } ovla_head_out_bwd_args;
 int ovla_head_out_bwd(const ovla_head_out_bwd_args* a, void* stream);
 
+/* The fused L1 / diffusion action-head tail (`north_star`: "a fused L1 action-head"): everything of MLPResNet.forward after fc1
+ * (prismatic/models/action_heads.py:72-81, 49-56) and the loss of finetune.py:400 / :407 in ONE launch, for up to 64 rows (batch 8 x chunk 8):
+ *     for b in 0, 1:   x <- x + relu(fc_b(LayerNorm_b(x)))           (MLPResNetBlock: ffn = LN -> Linear -> ReLU, residual outside)
+ *     h2 = LayerNorm_2(x);  pred = fc2(h2);  loss_sum += sum |pred - target|   (or squared, mse)
+ * dim / 16 <= 256 workgroups, all resident.  Five stages: LayerNorm rows of block 0 | GEMM 0 + epilogue | LayerNorm rows of block 1 | GEMM 1 +
+ * epilogue | LayerNorm 2 + fc2 + loss.  LayerNorm stages deal ROWS over the workgroups and write the normalised rows (hb: the Linear's saved
+ * input); GEMM stages deal 16-column strips: a workgroup streams ITS 16 weight rows from HBM once (each 33.5 MB matrix crosses HBM once,
+ * spread over the chip) and reads the R x dim normalised rows from L2, one wave per 16-row MFMA tile.  The stages are separated by four
+ * grid-wide barriers: agent-scope release / arrival counter / bounded spin / agent-scope acquire (the counter in `sync` is zeroed by a memset
+ * node ahead of the launch; a spin that runs out sets sync[1] and poisons pred and loss_sum with NaN instead of hanging).
+ * Arithmetic, rounding points AND summation orders are those of the unfused sequence (ovla_norm_fwd, ovla_gemm_bf16 with split_k = 2 and
+ * its reduce epilogue, ovla_head_out_fwd): results are bit-identical to it (tests/test_kernels_gpu.py).
+ * Everything the backward needs is written out when the pointers are given (training): per block the LayerNorm output hb (the Linear's
+ * saved input), the pre-activation zb and mean / rstd; h2, mean2, rstd2.  rows = R must be a multiple of 16 (<= 64; pad with zero rows),
+ * rows_real <= R rows enter pred / loss.  All [R, dim] buffers contiguous bf16; W_b [dim, dim] row-major [out, in]. */
+typedef struct {
+  const void* x0;                                   /* [R, dim] input of block 0 (= relu(fc1(LN1(.)))) */
+  const void* ln_w[2]; const void* ln_b[2]; const void* W[2]; const void* bias[2];
+  void* hb[2]; void* zb[2]; void* xo[2];            /* hb (LayerNorm output) and xo (block output) required; zb optional (training) */
+  float* mean[2]; float* rstd[2];                   /* optional, [R] */
+  const void* ln2_w; const void* ln2_b; void* h2; float* mean2; float* rstd2;   /* h2 required ([R, dim]); stats optional */
+  const void* W2; const void* b2; void* pred; const void* target; float* loss_sum;   /* W2 [adim, dim]; target / loss_sum optional */
+  uint32_t* sync;                                   /* device, >= 2 words: arrival counter, timeout flag */
+  int32_t rows, rows_real, dim, adim, mse, ksplit;  /* ksplit 1 | 2: accumulate K in that many halves, summed in order (= split_k of the unfused GEMM) */
+  float eps;
+} ovla_head_tail_args;
+int ovla_head_tail_fwd(const ovla_head_tail_args* a, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused AdamW over a flat parameter buffer (torch.optim.AdamW as called at finetune.py:952: betas (0.9,0.999),
  * eps 1e-8, weight_decay 0.01).  bf16 variant reproduces torch's per-op bf16 rounding sequence

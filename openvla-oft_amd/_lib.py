@@ -23,6 +23,8 @@ _CTYPE = {
     "int32_t*": ctypes.c_void_p,
     "int64_t*": ctypes.c_void_p,
     "uint8_t*": ctypes.c_void_p,
+    "uint32_t*": ctypes.c_void_p,
+    "uint32_t": ctypes.c_uint32,
     "double*": ctypes.c_void_p,
     "char*": ctypes.c_char_p,
     "int64_t": ctypes.c_int64,

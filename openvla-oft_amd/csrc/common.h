@@ -70,6 +70,10 @@ OVLA_DEV float act_grad(float z, int act) {
   }
 }
 
+// LayerNorm output element, y = (x - mean) * rstd * w + b in fp32 with ONE explicit fma (every kernel that normalises -- the row kernels of
+// elementwise.hip and the fused head tail of head_optim.hip -- goes through this function, so they agree bit for bit by construction).
+OVLA_DEV float ln_affine(float x, float mean, float rstd, float w, float b) { return __builtin_fmaf((x - mean) * rstd, w, b); }
+
 OVLA_DEV float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

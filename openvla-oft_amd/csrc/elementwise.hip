@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const bf16_bits* __restri
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float d = f[j] - mean;
-      ss += d * d;
+      ss = __builtin_fmaf(d, d, ss);      // explicit fma: the fused head-tail kernel (head_optim.hip) repeats this arithmetic bit for bit
     }
   }
   const float var = block_sum_256(ss, red) / (float)dim;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const bf16_bits* __restri
       float bfv[8];
       if (b) load8(b + c * 8, bfv);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (f[j] - mean) * rstd * wf[j] + (b ? bfv[j] : 0.f);
+      for (int j = 0; j < 8; ++j) o[j] = ln_affine(f[j], mean, rstd, wf[j], b ? bfv[j] : 0.f);
     }
     store8(yr + c * 8, o);
   }
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void norm_fwd_wave_kernel(const bf16_bits* __r
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float d = f[i][j] - mean;
-        ss += d * d;
+        ss = __builtin_fmaf(d, d, ss);
       }
     }
   const float rstd = rsqrtf(wave_sum(ss) / (float)dim + eps);
@@ -187,18 +187,17 @@ __global__ __launch_bounds__(256) void norm_fwd_wave_kernel(const bf16_bits* __r
         float bfv[8];
         if (b) load8(b + c * 8, bfv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f[i][j] - mean) * rstd * wf[j] + (b ? bfv[j] : 0.f);
+        for (int j = 0; j < 8; ++j) o[j] = ln_affine(f[i][j], mean, rstd, wf[j], b ? bfv[j] : 0.f);
       }
       store8(yr + c * 8, o);
     }
   }
 }
 
-// (A wave-per-row BACKWARD kernel like norm_fwd_wave_kernel existed; it was bit-exact on one stream but, with the second vision
-// tower's kernels running beside it on another stream, a handful of waves per launch computed their row with a slightly different
-// row mean of dy * w (1-2 bf16 ulp in the outputs; found with tools/determinism_check.py, not explained: neither the cross-lane
-// reduction, ds_bpermute or DPP, nor the load waits were at fault).  The workgroup-per-row norm_bwd_kernel below is stable under the same
-// concurrency and the step time is the same, so the backward uses it for every width.)
+// (A wave-per-row BACKWARD kernel like norm_fwd_wave_kernel existed in round 1.  Beside the second vision tower's kernels on another stream a
+// few waves per launch dropped one term of a per-lane running sum in lanes 48-63: the compiler's packed-FP32 code (v_pk_add_f32 fed by
+// v_mov_b32) under that co-issue pattern, root-caused in round 2 with tools/norm_bwd_wave_probe.py -- DESIGN.md "Run-to-run determinism".
+// The library is now built without packed FP32; the workgroup-per-row norm_bwd_kernel below stays because it costs the same.)
 
 // ---------------------------------------------------------------------------------------------------------------
 // RoPE tables and in-place rotation.  HF convention: cos/sin are fp32, cast to bf16; q' = bf16(bf16(q*c) + bf16(rot(q)*s)).

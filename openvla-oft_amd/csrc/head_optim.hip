@@ -47,6 +47,249 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const bf16_bits* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused head tail (ovla.h: ovla_head_tail_fwd).
+struct HeadTailParams {
+  const bf16_bits* x0;
+  const bf16_bits *ln_w[2], *ln_b[2], *W[2], *bias[2];
+  bf16_bits *hb[2], *zb[2], *xo[2];
+  float *mean[2], *rstd[2];
+  const bf16_bits *ln2_w, *ln2_b; bf16_bits* h2; float *mean2, *rstd2;
+  const bf16_bits *W2, *b2; bf16_bits* pred; const bf16_bits* target; float* loss_sum;
+  unsigned* sync;
+  int R, rows_real, D, adim, mse, ksplit;
+  float eps;
+};
+
+// One row of LayerNorm exactly as ovla_norm_fwd computes it (elementwise.hip): widths <= 1536 take norm_fwd_wave_kernel's form (one wave per
+// row, the row in registers, one butterfly sum), wider rows norm_fwd_kernel's (256 threads per row, chunks t, t + 256, ..., block_sum_256).
+// Writes y[row, :], optionally mean / rstd, and returns the thread's normalised values of chunks t and t + 256 (wide form) for the caller.
+OVLA_DEV float head_block_sum(float v, float* red) {   // block_sum_256 of elementwise.hip
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+OVLA_DEV void head_ln_row_wide(const bf16_bits* __restrict__ xr, bf16_bits* __restrict__ yr, const bf16_bits* __restrict__ w, const bf16_bits* __restrict__ b,
+                               float* mean_out, float* rstd_out, int D, float eps, float* red) {
+  const int nchunk = D >> 3;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
+    const bf16x8_bits q = *reinterpret_cast<const bf16x8_bits*>(xr + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += bf2f((bf16_bits)q[j]);
+  }
+  const float mean = head_block_sum(s, red) / (float)D;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
+    const bf16x8_bits q = *reinterpret_cast<const bf16x8_bits*>(xr + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = bf2f((bf16_bits)q[j]) - mean;
+      ss = __builtin_fmaf(d, d, ss);
+    }
+  }
+  const float var = head_block_sum(ss, red) / (float)D;
+  const float rstd = rsqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    if (mean_out) *mean_out = mean;
+    if (rstd_out) *rstd_out = rstd;
+  }
+  for (int c = threadIdx.x; c < nchunk; c += 256) {
+    const bf16x8_bits q = *reinterpret_cast<const bf16x8_bits*>(xr + c * 8);
+    const bf16x8_bits wq = *reinterpret_cast<const bf16x8_bits*>(w + c * 8), bq = *reinterpret_cast<const bf16x8_bits*>(b + c * 8);
+    bf16x8_bits o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(ln_affine(bf2f((bf16_bits)q[j]), mean, rstd, bf2f((bf16_bits)wq[j]), bf2f((bf16_bits)bq[j])));
+    *reinterpret_cast<bf16x8_bits*>(yr + c * 8) = o;
+  }
+}
+
+OVLA_DEV void head_ln_row_wave(const bf16_bits* __restrict__ xr, bf16_bits* __restrict__ yr, const bf16_bits* __restrict__ w, const bf16_bits* __restrict__ b,
+                               float* mean_out, float* rstd_out, int D, float eps, int lane) {
+  const int nchunk = D >> 3;
+  float s = 0.f;
+  for (int c = lane; c < nchunk; c += 64) {
+    const bf16x8_bits q = *reinterpret_cast<const bf16x8_bits*>(xr + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += bf2f((bf16_bits)q[j]);
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float ss = 0.f;
+  for (int c = lane; c < nchunk; c += 64) {
+    const bf16x8_bits q = *reinterpret_cast<const bf16x8_bits*>(xr + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = bf2f((bf16_bits)q[j]) - mean;
+      ss = __builtin_fmaf(d, d, ss);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+  if (lane == 0) {
+    if (mean_out) *mean_out = mean;
+    if (rstd_out) *rstd_out = rstd;
+  }
+  for (int c = lane; c < nchunk; c += 64) {
+    const bf16x8_bits q = *reinterpret_cast<const bf16x8_bits*>(xr + c * 8);
+    const bf16x8_bits wq = *reinterpret_cast<const bf16x8_bits*>(w + c * 8), bq = *reinterpret_cast<const bf16x8_bits*>(b + c * 8);
+    bf16x8_bits o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(ln_affine(bf2f((bf16_bits)q[j]), mean, rstd, bf2f((bf16_bits)wq[j]), bf2f((bf16_bits)bq[j])));
+    *reinterpret_cast<bf16x8_bits*>(yr + c * 8) = o;
+  }
+}
+
+// LayerNorm of all R rows, rows dealt over the grid (a whole workgroup per row for wide rows, a wave per row for narrow ones)
+OVLA_DEV void head_ln_rows(const bf16_bits* x, bf16_bits* y, const bf16_bits* w, const bf16_bits* b, float* mean, float* rstd, int R, int D, float eps, float* red) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (D > 1536) {
+    for (int m = blockIdx.x; m < R; m += gridDim.x)
+      head_ln_row_wide(x + (int64_t)m * D, y + (int64_t)m * D, w, b, mean ? mean + m : nullptr, rstd ? rstd + m : nullptr, D, eps, red);
+  } else {
+    for (int m = blockIdx.x * 4 + wave; m < R; m += gridDim.x * 4)
+      head_ln_row_wave(x + (int64_t)m * D, y + (int64_t)m * D, w, b, mean ? mean + m : nullptr, rstd ? rstd + m : nullptr, D, eps, lane);
+  }
+}
+
+// Grid-wide barrier, bounded: every workgroup's stores so far become visible to every workgroup's loads after it.  false = timed out.
+OVLA_DEV bool head_grid_barrier(unsigned* sync, unsigned target, int* flag) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 21)) {                       // ~ seconds: a grid that is not fully resident ends here instead of hanging
+        ok = 0;
+        __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *flag = ok;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+
+// Stages, separated by grid barriers:  LN rows of block 0 | GEMM 0 + epilogue | LN rows of block 1 | GEMM 1 + epilogue | LN 2 rows + fc2 + loss.
+// LayerNorm phases deal ROWS over the workgroups (each row normalised once, by ovla_norm_fwd's own arithmetic) and write the normalised
+// rows hb (the Linear's input, which the backward needs anyway); GEMM phases deal 16-column strips: a workgroup streams its 16 weight rows
+// from HBM once and reads the R x dim normalised rows from L2, one wave per 16-row tile.
+__global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailParams p) {
+  __shared__ float red[4][MAX_ADIM];
+  __shared__ int bar_ok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int R = p.R, D = p.D;
+  // wave -> (16-row tile mt, 16-column strip): with fewer than four row tiles the spare waves take further column strips of the same
+  // workgroup (R = 16: four strips per workgroup, grid = dim / 64), so every wave streams weights whatever the batch size
+  const int tiles_m = R / 16, strips = (tiles_m == 1) ? 4 : (tiles_m == 2 ? 2 : 1);
+  const int mt = wave % tiles_m, ns = wave / tiles_m;
+  const bool has_tile = ns < strips;
+  const int n0 = (blockIdx.x * strips + ns) * 16;
+  const unsigned G = gridDim.x;
+  unsigned epoch = 0;
+  auto barrier = [&]() -> bool {
+    if (head_grid_barrier(p.sync, G * (++epoch), &bar_ok)) return true;
+    if (blockIdx.x == 0 && tid == 0) {   // poison the results: a timed-out barrier must not look like a success
+      if (p.loss_sum) *p.loss_sum = __builtin_nanf("");
+      p.pred[0] = 0x7fc0;
+    }
+    return false;
+  };
+  const bf16_bits* xin = p.x0;
+  for (int b = 0; b < 2; ++b) {
+    head_ln_rows(xin, p.hb[b], p.ln_w[b], p.ln_b[b], p.mean[b], p.rstd[b], R, D, p.eps, &red[0][0]);
+    if (!barrier()) return;
+    if (has_tile) {   // rows 16 mt .. +15 x columns n0 .. +15, K = D in `ksplit` halves summed in order
+      const int row = mt * 16 + (lane & 15), kq = 8 * (lane >> 4);
+      const bf16_bits* hr = p.hb[b] + (int64_t)row * D;
+      const bf16_bits* wr = p.W[b] + (int64_t)(n0 + (lane & 15)) * D;
+      const int ksteps = D / 32;
+      const int half = p.ksplit > 1 ? ((D / 64 + 1) / 2) * 2 : ksteps;       // gemm_nt's split: ceil(T / 2) K tiles of 64 = 2 k-steps each
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+      // the two halves are independent accumulation chains: they run interleaved (twice the loads in flight, the matrix pipe never waits
+      // on one chain), each in its own k order, so the sums are those of the two split-K workgroups of the unfused GEMM
+      const int n_hi = ksteps - half;              // k-steps of the second half (0 when ksplit == 1; <= half)
+#pragma unroll 4
+      for (int ks = 0; ks < half && ks < ksteps; ++ks) {
+        const int k = ks * 32 + kq;
+        const bf16x8_bits a0 = *reinterpret_cast<const bf16x8_bits*>(hr + k);
+        const bf16x8_bits w0 = *reinterpret_cast<const bf16x8_bits*>(wr + k);
+        if (ks < n_hi) {
+          const bf16x8_bits a1 = *reinterpret_cast<const bf16x8_bits*>(hr + k + half * 32);
+          const bf16x8_bits w1 = *reinterpret_cast<const bf16x8_bits*>(wr + k + half * 32);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, a1, acc[1], 0, 0, 0);
+        }
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, a0, acc[0], 0, 0, 0);
+      }
+      // epilogue = epilogue_store of gemm_nt.hip after its split-K reduce: (0 + p0) + p1, + bias, round, save z, ReLU, round, + residual, round
+      const int n = n0 + 4 * (lane >> 4);
+      const f32x4 v = p.ksplit > 1 ? (acc[0] + acc[1]) : acc[0];
+      const bf16x4_bits bb = *reinterpret_cast<const bf16x4_bits*>(p.bias[b] + n);
+      const bf16x4_bits rr = *reinterpret_cast<const bf16x4_bits*>(xin + (int64_t)row * D + n);
+      bf16x4_bits z, o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = bfround(v[j] + bf2f((bf16_bits)bb[j]));
+        z[j] = (short)f2bf(t);
+        t = bfround(t > 0.f ? t : 0.f);
+        o[j] = (short)f2bf(bfround(t + bf2f((bf16_bits)rr[j])));
+      }
+      if (p.zb[b]) *reinterpret_cast<bf16x4_bits*>(p.zb[b] + (int64_t)row * D + n) = z;
+      *reinterpret_cast<bf16x4_bits*>(p.xo[b] + (int64_t)row * D + n) = o;
+    }
+    if (!barrier()) return;
+    xin = p.xo[b];
+  }
+  // ---- LayerNorm 2 -> h2 (rows over the grid), then fc2 + loss per row (ovla_head_out_fwd's arithmetic on the bf16 h2 the row's owner wrote) ----
+  head_ln_rows(xin, p.h2, p.ln2_w, p.ln2_b, p.mean2, p.rstd2, R, D, p.eps, &red[0][0]);
+  if (D <= 1536) {   // narrow rows were normalised one per WAVE, possibly by other workgroups: one more barrier before the row dot products
+    if (!barrier()) return;
+  } else {
+    __syncthreads();  // wide rows: row m was written by THIS workgroup (rows are dealt m = blockIdx.x, + G, ... in both loops)
+  }
+  for (int m = blockIdx.x; m < p.rows_real; m += G) {
+    float acc[MAX_ADIM];
+#pragma unroll
+    for (int a = 0; a < MAX_ADIM; ++a) acc[a] = 0.f;
+    for (int c = tid * 8; c < D; c += 256 * 8) {
+      const bf16x8_bits xv = *reinterpret_cast<const bf16x8_bits*>(p.h2 + (int64_t)m * D + c);
+#pragma unroll
+      for (int a = 0; a < MAX_ADIM; ++a) {
+        if (a < p.adim) {
+          const bf16x8_bits wv = *reinterpret_cast<const bf16x8_bits*>(p.W2 + (int64_t)a * D + c);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[a] += bf2f((bf16_bits)xv[j]) * bf2f((bf16_bits)wv[j]);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < MAX_ADIM; ++a) {
+      const float sa = wave_sum(acc[a]);
+      if (lane == 0) red[wave][a] = sa;
+    }
+    __syncthreads();
+    if (tid < p.adim) {
+      const int a = tid;
+      float v = red[0][a] + red[1][a] + red[2][a] + red[3][a];
+      v = bfround(v + (p.b2 ? bf2f(p.b2[a]) : 0.f));
+      p.pred[(int64_t)m * p.adim + a] = f2bf(v);
+      if (p.target && p.loss_sum) {
+        const float d = bfround(bf2f(p.target[(int64_t)m * p.adim + a]) - v);
+        atomicAdd(p.loss_sum, p.mse ? bfround(d * d) : fabsf(d));
+      }
+    }
+  }
+}
+
 // column-parallel backward: thread owns column c.  dpred[m,a] = bf16(sign(pred-target) * scale) (L1) or
 // bf16(2 (pred-target) * scale) (MSE);  dx[m,c] = sum_a dpred[m,a] W[a,c];  dW[a,c] += sum_m dpred[m,a] x[m,c]
 __global__ __launch_bounds__(256) void head_out_bwd_kernel(const bf16_bits* __restrict__ x, const bf16_bits* __restrict__ W,
@@ -220,6 +463,35 @@ extern "C" int ovla_head_out_fwd(const ovla_head_out_fwd_args* a, void* stream_)
   hipLaunchKernelGGL(head_out_fwd_kernel, dim3(a->rows), dim3(256), 0, stream, (const bf16_bits*)a->x, (const bf16_bits*)a->W,
                      (const bf16_bits*)a->b, (bf16_bits*)a->pred, (const bf16_bits*)a->target, a->loss_sum, a->dim, a->adim, a->mse);
   OVLA_CHECK_LAUNCH("ovla_head_out_fwd");
+  return OVLA_OK;
+}
+
+extern "C" int ovla_head_tail_fwd(const ovla_head_tail_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(a && a->x0 && a->xo[0] && a->xo[1] && a->hb[0] && a->hb[1] && a->h2 && a->W2 && a->pred && a->sync && a->ln2_w && a->ln2_b, "ovla_head_tail_fwd: null pointer");
+  for (int b = 0; b < 2; ++b)
+    OVLA_REQUIRE(a->ln_w[b] && a->ln_b[b] && a->W[b] && a->bias[b], "ovla_head_tail_fwd: block %d needs LayerNorm weight / bias and Linear weight / bias", b);
+  OVLA_REQUIRE(a->rows >= 16 && a->rows <= 64 && (a->rows % 16) == 0 && a->rows_real >= 1 && a->rows_real <= a->rows, "ovla_head_tail_fwd: rows=%d (multiple of 16, <= 64) rows_real=%d",
+               a->rows, a->rows_real);
+  OVLA_REQUIRE(a->dim >= 64 && (a->dim % 64) == 0 && a->dim / 16 <= 256 && (a->dim / 16) % 4 == 0, "ovla_head_tail_fwd: dim=%d must be a multiple of 64 and <= 4096 (one resident workgroup per 16 columns)", a->dim);
+  OVLA_REQUIRE(a->adim > 0 && a->adim <= MAX_ADIM && (a->ksplit == 1 || a->ksplit == 2), "ovla_head_tail_fwd: adim=%d ksplit=%d", a->adim, a->ksplit);
+  OVLA_REQUIRE(aligned16(a->x0) && aligned16(a->xo[0]) && aligned16(a->xo[1]) && aligned16(a->h2) && aligned16(a->W[0]) && aligned16(a->W[1]) && aligned16(a->W2) &&
+               aligned16(a->ln_w[0]) && aligned16(a->ln_b[0]) && aligned16(a->ln_w[1]) && aligned16(a->ln_b[1]) && aligned16(a->ln2_w) && aligned16(a->ln2_b) &&
+               (!a->hb[0] || aligned16(a->hb[0])) && (!a->hb[1] || aligned16(a->hb[1])), "ovla_head_tail_fwd: 16-byte alignment");
+  OVLA_REQUIRE((((uintptr_t)a->bias[0] | (uintptr_t)a->bias[1]) & 7) == 0 && (!a->zb[0] || aligned16(a->zb[0])) && (!a->zb[1] || aligned16(a->zb[1])), "ovla_head_tail_fwd: bias / zb alignment");
+  HeadTailParams p;
+  p.x0 = (const bf16_bits*)a->x0;
+  for (int b = 0; b < 2; ++b) {
+    p.ln_w[b] = (const bf16_bits*)a->ln_w[b]; p.ln_b[b] = (const bf16_bits*)a->ln_b[b]; p.W[b] = (const bf16_bits*)a->W[b]; p.bias[b] = (const bf16_bits*)a->bias[b];
+    p.hb[b] = (bf16_bits*)a->hb[b]; p.zb[b] = (bf16_bits*)a->zb[b]; p.xo[b] = (bf16_bits*)a->xo[b]; p.mean[b] = a->mean[b]; p.rstd[b] = a->rstd[b];
+  }
+  p.ln2_w = (const bf16_bits*)a->ln2_w; p.ln2_b = (const bf16_bits*)a->ln2_b; p.h2 = (bf16_bits*)a->h2; p.mean2 = a->mean2; p.rstd2 = a->rstd2;
+  p.W2 = (const bf16_bits*)a->W2; p.b2 = (const bf16_bits*)a->b2; p.pred = (bf16_bits*)a->pred; p.target = (const bf16_bits*)a->target; p.loss_sum = a->loss_sum;
+  p.sync = a->sync; p.R = a->rows; p.rows_real = a->rows_real; p.D = a->dim; p.adim = a->adim; p.mse = a->mse; p.ksplit = a->ksplit; p.eps = a->eps;
+  if (hipMemsetAsync(a->sync, 0, 2 * sizeof(uint32_t), stream) != hipSuccess) { ovla_set_error("ovla_head_tail_fwd: hipMemsetAsync failed"); return OVLA_ELAUNCH; }
+  const int tiles_m = a->rows / 16, strips = tiles_m == 1 ? 4 : (tiles_m == 2 ? 2 : 1);
+  hipLaunchKernelGGL(head_tail_kernel, dim3(a->dim / 16 / strips), dim3(256), 0, stream, p);
+  OVLA_CHECK_LAUNCH("ovla_head_tail_fwd");
   return OVLA_OK;
 }
 

@@ -39,6 +39,13 @@ _FUSE = os.environ.get("OVLA_FUSE_DACT", "none")
 # The INVERSE RoPE of the backward, which needs no loads beyond the tables and no LDS (attention-backward epilogue), is on: -0.6 ms.
 _FUSE_ROPE_FWD = os.environ.get("OVLA_FUSE_ROPE_FWD", "1") == "1"
 _FUSE_ACT, _FUSE_SWIGLU = _FUSE in ("act", "all"), _FUSE in ("swiglu", "all")
+# The action head's tail (two MLPResNet blocks, LayerNorm 2, fc2, L1 / MSE loss) as ONE launch for up to 64 rows (ovla_head_tail_fwd),
+# bit-identical to the unfused eight-launch sequence, so the switch is invisible in the numbers.  Measured: at 64 rows
+# (the fine-tune step) the two are equal within run-to-run noise (168.5 / 169.2 vs 168.1 / 168.7 ms/step, alternated); at 8 rows inside
+# the hipGraph-replayed inference chunk the fused kernel is 50 us SLOWER (15.75 / 15.83 vs 15.70 / 15.78 ms) -- four grid-wide barriers cost
+# more than the kernel boundaries they replace (a boundary is 1.5-1.9 us on this chip).  Default: fused for more than 16 rows, unfused below;
+# OVLA_FUSE_HEAD=0 / 1 forces one path everywhere.
+_FUSE_HEAD = {"0": False, "1": True}.get(os.environ.get("OVLA_FUSE_HEAD", "auto"), None)
 
 
 # ======================================================================================================================
@@ -556,6 +563,28 @@ class ActionHead:
         z1 = torch.empty((rows, cfg.llm_dim), dtype=BF16, device=x0.device) if train else None
         split = 8 if rows <= 256 else 1      # small-M weight stream: split K over the chip
         x, s1 = self.fc1.fwd(h0, act=ops.ACT_RELU, c_pre=z1, split_k=split)
+        D = cfg.llm_dim
+        if (rows > 16 if _FUSE_HEAD is None else _FUSE_HEAD) and rows <= 64 and D % 64 == 0 and D // 16 <= 256 and (D // 16) % 4 == 0:
+            # everything after fc1 -- both MLPResNet blocks, LayerNorm 2, fc2 and the loss -- is ONE launch (ovla_head_tail_fwd), bit-identical
+            # to the unfused sequence below; its backward is the unfused one, fed from the tensors the kernel saves
+            R = (rows + 15) // 16 * 16
+            if R != rows:
+                xp = torch.zeros((R, D), dtype=BF16, device=x.device)
+                xp[:rows] = x
+                x_in = xp
+            else:
+                x_in = x
+            if getattr(self, "_sync", None) is None:
+                self._sync = torch.zeros(2, dtype=torch.int32, device=x.device)
+            loss_sum = torch.zeros(1, dtype=F32, device=x0.device) if target is not None else None
+            o = ops.head_tail_fwd(x_in, [(b["ln_w"].data, b["ln_b"].data, b["fc"].Wc, b["fc"].bc) for b in self.blocks], (self.ln2_w.data, self.ln2_b.data),
+                                  self.out_w.data, self.out_b.data, rows_real=rows_real, target=target, loss_sum=loss_sum, mse=mse, train=train, sync=self._sync)
+            saved = None
+            if train:
+                xs = [x_in[:rows], o["xo"][0][:rows]]
+                blocks_saved = [(xs[b], o["mean"][b][:rows], o["rstd"][b][:rows], o["zb"][b][:rows], (o["hb"][b][:rows],)) for b in range(2)]
+                saved = (x0, m0, r0, z1, s1, blocks_saved, o["xo"][1][:rows], o["mean2"][:rows], o["rstd2"][:rows], o["h2"][:rows], o["pred"], target, mse, rows_real)
+            return o["pred"], loss_sum, saved
         blocks_saved = []
         for b in self.blocks:
             hb, mb, rb = ops.norm_fwd(x, b["ln_w"].data, b["ln_b"].data, eps=1e-5, rms=False, save_stats=train)

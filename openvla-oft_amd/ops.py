@@ -566,6 +566,37 @@ def head_out_fwd(x, W, b, target=None, loss_sum=None, mse=False):
     return pred
 
 
+def head_tail_fwd(x0, blocks, ln2, out_w, out_b, *, rows_real, target=None, loss_sum=None, mse=False, train=False, sync=None, ksplit=2, eps=1e-5):
+    """The fused action-head tail (ovla.h: ovla_head_tail_fwd): x0 bf16 [R, D] (R a multiple of 16, <= 64) -> two MLPResNet blocks, LayerNorm 2,
+    fc2 and the loss in one launch.  blocks = [(ln_w, ln_b, W [D, D], bias)] * 2, ln2 = (w, b).  Returns a dict with pred [rows_real, adim] and
+    everything the (unfused) backward reads: per block hb, zb, x_out, mean, rstd (hb / zb / stats only when train), h2, mean2, rstd2."""
+    _chk(x0)
+    R, D = x0.shape
+    assert x0.is_contiguous() and len(blocks) == 2
+    dev = x0.device
+    adim = out_w.shape[0]
+    new = lambda: torch.empty((R, D), dtype=BF16, device=dev)  # noqa: E731
+    stat = lambda: torch.empty(R, dtype=torch.float32, device=dev)  # noqa: E731
+    out = dict(hb=[new(), new()], zb=[new() if train else None for _ in range(2)], xo=[new(), new()],
+               mean=[stat() if train else None for _ in range(2)], rstd=[stat() if train else None for _ in range(2)], h2=new(),
+               mean2=stat() if train else None, rstd2=stat() if train else None, pred=torch.empty((rows_real, adim), dtype=BF16, device=dev))
+    if sync is None:
+        sync = torch.zeros(2, dtype=torch.int32, device=dev)
+    g = STRUCTS["ovla_head_tail_args"]()
+    g.x0 = x0.data_ptr()
+    for b, (lw, lb, W, bias) in enumerate(blocks):
+        assert tuple(W.shape) == (D, D) and W.is_contiguous() and lw.numel() == D and lb.numel() == D and bias.numel() == D
+        g.ln_w[b], g.ln_b[b], g.W[b], g.bias[b] = lw.data_ptr(), lb.data_ptr(), W.data_ptr(), bias.data_ptr()
+        g.hb[b], g.zb[b], g.xo[b] = _p(out["hb"][b]), _p(out["zb"][b]), out["xo"][b].data_ptr()
+        g.mean[b], g.rstd[b] = _p(out["mean"][b]), _p(out["rstd"][b])
+    g.ln2_w, g.ln2_b, g.h2, g.mean2, g.rstd2 = ln2[0].data_ptr(), ln2[1].data_ptr(), out["h2"].data_ptr(), _p(out["mean2"]), _p(out["rstd2"])
+    g.W2, g.b2, g.pred, g.target, g.loss_sum = out_w.data_ptr(), _p(out_b), out["pred"].data_ptr(), _p(target), _p(loss_sum)
+    g.sync, g.rows, g.rows_real, g.dim, g.adim, g.mse, g.ksplit, g.eps = sync.data_ptr(), R, rows_real, D, adim, int(mse), ksplit, eps
+    _lib.call("ovla_head_tail_fwd", g, _stream())
+    out["sync"] = sync
+    return out
+
+
 def head_out_bwd(x, W, pred, target, dloss_scale, dW, db, mse=False, dpred=None):
     """Backward of the head tail.  Either (pred, target, dloss_scale) -- fused L1/MSE gradient -- or an explicit dpred."""
     rows, dim = x.shape

@@ -622,3 +622,69 @@ def test_token_ce(ops, dev, rows, vocab, ld):
     assert d2.data_ptr() == dl.data_ptr() and torch.equal(d2[:, :vocab], d[:, :vocab]) and torch.equal(l2, loss_rows) and torch.equal(a2, amax)
     if ld > vocab:
         assert torch.equal(dl[:, vocab:].cpu(), logits[:, vocab:])                                 # columns past the vocabulary are untouched
+
+
+@pytest.mark.parametrize("D,rows,adim,mse,train", [(256, 24, 7, False, True), (256, 8, 7, True, False), (4096, 64, 7, False, True), (4096, 8, 7, False, False),
+                                                   (1024, 56, 14, True, True)])
+def test_fused_head_tail_is_bit_identical_to_the_unfused_sequence(dev, D, rows, adim, mse, train):
+    """ovla_head_tail_fwd (two MLPResNet blocks -> LayerNorm 2 -> fc2 -> L1 / MSE loss in ONE launch, grid-wide barriers between the stages)
+    against the unfused kernel sequence the engine ran before (ovla_norm_fwd, ovla_gemm_bf16 split_k = 2 + reduce epilogue, ovla_head_out_fwd):
+    predictions, loss and EVERY tensor saved for the backward are bit-identical; and against plain torch fp32 within bf16 tolerance."""
+    import dataclasses
+    import importlib
+    import os
+
+    load = importlib.import_module
+    engine_mod, config_mod = load("openvla-oft_amd.engine"), load("openvla-oft_amd.config")
+    cfg = dataclasses.replace(config_mod.OPENVLA_7B, llm_dim=D, action_dim=adim, chunk=rows)        # one "sample" of `rows` chunk steps
+    g = torch.Generator().manual_seed(D + rows)
+    sd = {}
+    hp = "action_head.model."
+    for nm, dim in (("layer_norm1", D * adim), ("layer_norm2", D), ("mlp_resnet_blocks.0.ffn.0", D), ("mlp_resnet_blocks.1.ffn.0", D)):
+        sd[hp + nm + ".weight"], sd[hp + nm + ".bias"] = 1 + 0.1 * torch.randn(dim, generator=g), 0.05 * torch.randn(dim, generator=g)
+    for nm, o, i in (("fc1", D, D * adim), ("mlp_resnet_blocks.0.ffn.1", D, D), ("mlp_resnet_blocks.1.ffn.1", D, D), ("fc2", adim, D)):
+        sd[hp + nm + ".weight"], sd[hp + nm + ".bias"] = torch.randn(o, i, generator=g) * (1.0 / i ** 0.5), 0.02 * torch.randn(o, generator=g)
+    get = lambda n: sd[n].to(dev, BF)  # noqa: E731
+    head = engine_mod.build_component(engine_mod.ActionHead, dev, get, hp, cfg=cfg)
+    ah = (torch.randn(rows * adim, D, generator=g) * 0.7).to(dev, BF)
+    tgt = (torch.rand(rows, adim, generator=g) * 2 - 1).to(dev, BF)
+    outs = {}
+    for fused in (True, False):
+        engine_mod._FUSE_HEAD = fused
+        try:
+            pred, loss_sum, saved = head.fwd(ah, target=tgt, mse=mse, train=train)
+        finally:
+            engine_mod._FUSE_HEAD = {"0": False, "1": True}.get(os.environ.get("OVLA_FUSE_HEAD", "auto"), None)
+        torch.cuda.synchronize()
+        outs[fused] = (pred.clone(), loss_sum.clone(), saved)
+    assert int(head._sync[1].item()) == 0, "a grid barrier of the fused kernel timed out"
+    (pf, lf, sf), (pu, lu, su) = outs[True], outs[False]
+    assert torch.equal(pf, pu), f"pred: {(pf != pu).sum().item()} of {pf.numel()} differ"
+    assert abs(lf.item() - lu.item()) <= 1e-6 * max(1.0, abs(lu.item())), "loss: same addends, atomic order only"
+    if train:
+        names = ["x0", "m0", "r0", "z1", "s1", "blocks", "x_last", "m2", "r2", "h2", "pred"]
+        for nm, a, b in zip(names, sf, su):
+            if nm == "blocks":
+                for bi, (ba, bb) in enumerate(zip(a, b)):
+                    for k, (ta, tb) in enumerate(zip(ba[:4] + ba[4], bb[:4] + bb[4])):
+                        assert torch.equal(ta, tb), f"block {bi} saved tensor {k}: {(ta != tb).sum().item()} differ"
+            elif torch.is_tensor(a):
+                assert torch.equal(a, b), f"{nm}: {(a != b).sum().item()} of {a.numel()} differ"
+        # and the backward runs off the fused kernel's saved tensors
+        head.store.zero_grad()
+        d1 = head.bwd(sf).clone()
+        g1 = {k: v.clone() for k, v in head.store.flat_grad.items()}
+        head.store.zero_grad()
+        d2 = head.bwd(su)
+        assert torch.equal(d1, d2) and all(torch.allclose(g1[k], head.store.flat_grad[k], rtol=1e-5, atol=1e-7) for k in g1)
+    # plain torch fp32 reference of the same head
+    x = ah.float().cpu().view(rows, adim * D)
+    F = torch.nn.functional
+    w = lambda n: sd[hp + n].to(BF).float()  # noqa: E731
+    h = F.relu(F.linear(F.layer_norm(x, (adim * D,), w("layer_norm1.weight"), w("layer_norm1.bias"), 1e-5), w("fc1.weight"), w("fc1.bias")))
+    for b in range(2):
+        q = f"mlp_resnet_blocks.{b}.ffn."
+        h = h + F.relu(F.linear(F.layer_norm(h, (D,), w(q + "0.weight"), w(q + "0.bias"), 1e-5), w(q + "1.weight"), w(q + "1.bias")))
+    ref = F.linear(F.layer_norm(h, (D,), w("layer_norm2.weight"), w("layer_norm2.bias"), 1e-5), w("fc2.weight"), w("fc2.bias"))
+    err = (pf.float().cpu() - ref).abs().max().item()
+    assert err < 3e-2 * max(1.0, ref.abs().max().item()), err
