@@ -19,14 +19,19 @@ PROFILE = None
 
 _WS_BYTES = 96 << 20   # persistent fp32 scratch per device for split-K / hybrid-schedule partial sums (stream-ordered reuse)
 _ws_cache = {}
+_ws_retired = []       # outgrown workspaces stay allocated: a captured hipGraph (engine.ChunkGraph) has their raw pointers in its kernel arguments
 
 
 def _workspace(device, nbytes):
     """One scratch buffer per (device, stream): launches on one stream reuse it in stream order; the two vision towers run
-    on different streams and must not share partial-sum slabs."""
+    on different streams and must not share partial-sum slabs.  A buffer that has been handed out is never freed: when a call needs more
+    than the current one holds, a larger one takes its place for LATER launches and the old one is retired, not released -- graph replays
+    recorded earlier keep writing into memory they still own."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
+        if ws is not None:
+            _ws_retired.append(ws)
         ws = torch.empty(max(nbytes, _WS_BYTES) // 4, dtype=torch.float32, device=device)
         _ws_cache[key] = ws
     return ws
