@@ -75,8 +75,9 @@ def test_full_size_forward_stage_by_stage(full, dev, B):
             continue
         yard = max(row["native"][1], row["bf16"][1])
         assert row["hip"][1] <= 1.25 * yard + 1e-3, f"{name}: hip rel-L2 {row['hip'][1]:.3e} vs the bf16 evaluations' {yard:.3e}"
-    # continuous actions, in action units (|a| <= O(1)): no further from exact arithmetic than the reference's own eager path
-    assert table["pred"]["hip"][0] <= 1.25 * max(table["pred"]["native"][0], table["pred"]["bf16"][0]) + 2 * ULP
+    # continuous actions, in action units: rel-L2 is covered by the loop above (x1.25); the L-inf over B x 56 numbers is a noisy statistic (at
+    # B = 1 the HIP path's own value moved 0.35 .. 0.46 between builds that differ by one fma, the eager path's 0.28 .. 0.76 between runs): x2
+    assert table["pred"]["hip"][0] <= 2.0 * max(table["pred"]["native"][0], table["pred"]["bf16"][0]) + 2 * ULP
     # (between two bf16 evaluations the distance is up to the sum of their distances to fp32; at B = 1 -- 56 numbers -- the eager path's own
     # distance varies 0.28 .. 0.76 between runs and boxes, so the yardstick is twice the worse of the two reference evaluations)
     assert hip_vs_native <= 2.0 * max(table["pred"]["native"][0], table["pred"]["bf16"][0]) + 2 * ULP
