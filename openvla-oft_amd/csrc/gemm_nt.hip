@@ -51,6 +51,7 @@ struct GemmParams {
   const bf16_bits* dact_src; int64_t ld_dact; int dact_mode, dact_act;   // backward epilogues (ovla.h)
   const bf16_bits *rope_cos, *rope_sin; int rope_S, rope_cols;           // forward RoPE on columns [0, rope_cols), head_dim 128
   int fast_epi;  // host: no FiLM / backward epilogue / RoPE and 16-byte aligned operands -> the unrolled read-back path applies
+  int fast_swiglu_bwd;  // host: dact_mode 2 with 16-byte aligned [M, 2N] operands and nothing else in the epilogue -> SwiGLU' in the unrolled read-back
   int dbg;  // timing ablations, compiled in ONLY with -DOVLA_GEMM_ABLATE (build.sh ablate -> libovla_hip_ablate.so, tools/gemm_ablate.py): bit0 = stage only the first two K tiles, bit1 = read fragments once, bit2 = every workgroup stages tile (0,0): all L2 hits, bit3 = no epilogue, bit4 = epilogue without its stores, bit5 = nontemporal stores, bit6 = force the LDS-staged epilogue
   int full_tiles, rem_tiles, rem_splits;  // hybrid schedule: tiles >= full_tiles are split rem_splits ways along K
 };
@@ -445,6 +446,43 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   // 11-17 % of a 256x256 tile's time and 44 % of a ViT fc1 launch: bias + GELU + pre-activation save.)
   // (the 256x256 configs hold 128 accumulator registers: unrolling the activation code there spills, and no 256x256-tiled GEMM of
   // this model has an activation -- those keep the alpha / bias / residual subset)
+  if ((WTN % 8) == 0 && p.fast_swiglu_bwd && m0 + BM <= p.M && n0 + BN <= p.N) {
+    // SwiGLU backward in the unrolled read-back (swiglu_bwd_kernel's arithmetic on the bf16-rounded d h, as epilogue_store's dact_mode 2): this
+    // tile of d h = dy . W_down yields d gate AND d up for its columns; gate / up come from the saved [M, 2N] projection output.
+    constexpr int OCT = WTN / 8;
+    constexpr int STEPS = RM * 16 * OCT / 64;
+    const int mbase = m0 + wm * WTM, nbase = n0 + wn * WTN;
+    __syncthreads();
+#pragma unroll
+    for (int round = 0; round < MT / RM; ++round) {
+#pragma unroll
+      for (int ii = 0; ii < RM; ++ii)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          *reinterpret_cast<f32x4*>(wstage + (ii * 16 + (lane & 15)) * LDSW + j * 16 + 4 * (lane >> 4)) = acc[round * RM + ii][j];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st) {
+        const int idx = st * 64 + lane, row = idx / OCT, c8 = idx % OCT;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(wstage + row * LDSW + c8 * 8), hi = *reinterpret_cast<const f32x4*>(wstage + row * LDSW + c8 * 8 + 4);
+        const int m = mbase + round * RM * 16 + row, n = nbase + c8 * 8;
+        const bf16x8_bits g8 = *reinterpret_cast<const bf16x8_bits*>(p.dact_src + (int64_t)m * p.ld_dact + n);
+        const bf16x8_bits u8 = *reinterpret_cast<const bf16x8_bits*>(p.dact_src + (int64_t)m * p.ld_dact + p.N + n);
+        bf16x8_bits dg, du;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = bfround((e < 4 ? lo[e] : hi[e - 4]) * p.alpha), g = bf2f((bf16_bits)g8[e]), u = bf2f((bf16_bits)u8[e]);
+          const float sg = sigmoidf_(g);
+          du[e] = (short)f2bf(d * bfround(g * sg));
+          dg[e] = (short)f2bf(d * u * (sg * (1.f + g * (1.f - sg))));
+        }
+        *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = dg;
+        *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + p.N + n) = du;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
   if constexpr (WN == 4 && WTN == 64 && BN == 256) {
     if (rope_tile) {   // RoPE in the unrolled read-back (host guarantees an interior tile, alpha only, 16-byte aligned tables)
       constexpr int STEPS = RM * 16 * 8 / 64;
@@ -1144,6 +1182,8 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   OVLA_REQUIRE(a->tile < 1000, "ovla_gemm_bf16: tile %d selects a timing ablation; this library was built without OVLA_GEMM_ABLATE", a->tile);
   p.dbg = 0;
 #endif
+  p.fast_swiglu_bwd = a->dact_src && a->dact_mode == 2 && !a->bias && !a->residual && !a->colscale && !a->film_gamma && !a->C_pre && !a->rope_cos &&
+                      a->act == OVLA_ACT_NONE && (((uintptr_t)a->dact_src | (uintptr_t)a->C) & 15) == 0 && (a->ld_dact % 8) == 0 && (a->ldc % 8) == 0 && (a->N % 8) == 0;
   const bool rope_plain = !a->bias && !a->C_pre && !a->colscale && !a->residual && !a->film_gamma && !a->dact_src && a->act == OVLA_ACT_NONE;
   p.fast_epi = !a->film_gamma && !a->dact_src && !a->rope_cos && (!a->C_pre || (((uintptr_t)a->C_pre) & 15) == 0) &&
                (!a->colscale || (((uintptr_t)a->colscale) & 15) == 0) &&

@@ -30,7 +30,8 @@ F32 = torch.float32
 # Which activation derivatives ride in the data-gradient GEMM's epilogue (ovla.h "backward epilogues"): none | act | swiglu | all.
 # Bit-identical to the separate act_bwd / swiglu_bwd kernels and it saves the dh round trip, but measured on MI355X it is NOT faster
 # (B = 8: none 177.1-177.6 ms/step, act 177.5-178.0, swiglu 178.0, all 178.1-178.4): a 256x256 tile owns its CU, so the extra epilogue
-# traffic is exposed, while the separate elementwise kernels already run at the HBM roofline.  Default: separate kernels.
+# traffic is exposed, while the separate elementwise kernels already run at the HBM roofline.  Round 2 moved SwiGLU' into the UNROLLED epilogue
+# (gemm_nt.hip fast_swiglu_bwd): still no gain (170.0 / 170.4 with vs 170.5 / 170.3 without).  Default: separate kernels.
 _FUSE = os.environ.get("OVLA_FUSE_DACT", "none")
 # The forward RoPE rides in the q|k|v projection's epilogue (bit-identical to the separate rope pass).  Round 1 had it only in the 4x2-wave
 # layout's ROLLED epilogue, where it cost more than the 33 us pass it replaced (177.8-178.0 vs 176.7-177.0 ms/step) and was left off; round 2
