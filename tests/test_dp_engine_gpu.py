@@ -80,7 +80,7 @@ def _rel2(a, b):
     return ((a - b).norm() / (b.norm() + 1e-20)).item()
 
 
-@pytest.mark.parametrize("overlap,comm_dtype", [(True, "param"), (False, "fp32")])
+@pytest.mark.parametrize("overlap,comm_dtype", [(True, "param"), (False, "fp32"), (True, "fp32")])   # the last two: OVLA_DP_OVERLAP = 0 vs 1 at the same wire dtype
 def test_two_ranks_half_batch_equal_one_rank_full_batch(dev, tmp_path, overlap, comm_dtype):
     import torch.multiprocessing as mp
 
