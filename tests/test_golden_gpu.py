@@ -103,3 +103,45 @@ def test_g11_config1_plumbing_fixture(dev):
     err = np.abs(act - g["actions"]).max()
     print(f"G11: actions Linf vs recorded fp32 actions {err:.3e}")
     assert act.shape == (8, 7) and err < 6e-2
+
+
+def test_g13_get_vla_action_on_the_reference_observation(dev):
+    """BASELINE.json configs[0] / [1] on the reference's OWN observation (sample_libero_spatial_observation.pkl, extracted without unpickling):
+    `get_vla_action(cfg, vla, processor, obs, task_label, action_head, proprio_projector)` through the HIP path -- device center crop + dual
+    normalisation (ovla_image_prep), proprio normalisation (in place, like the reference), prompt built from the task description, one chunk,
+    un-normalisation -- against the oracle running the reference plumbing on the same arrays.  The reduced-width model keeps the real
+    224 x 224 / 256-patch geometry."""
+    import types
+
+    utils, modeling, config_mod = load("openvla-oft_amd.experiments.robot.openvla_utils"), load("openvla-oft_amd.modeling"), load("openvla-oft_amd.config")
+    g = fixture("g13_libero_observation.npz")
+    ocfg = vo.tiny_config()
+    ocfg.dino.image_size = ocfg.siglip.image_size = 224                      # 16 x 16 patches per image like OpenVLA-7B
+    sd = {k: v.to(BF).float() for k, v in vo.random_state_dict(ocfg, seed=0).items()}
+    cfg = config_mod.VLAConfig.from_any(ocfg)
+    pstats = {"q01": [-0.5, -0.4, 0.8, 2.5, -0.5, -0.5, 0.0, -0.05], "q99": [0.3, 0.4, 1.4, 3.6, 0.5, 0.3, 0.05, 0.0]}
+    astats = {"q01": [-0.9, -0.8, -0.9, -0.1, -0.2, -0.3, 0.0], "q99": [0.9, 0.7, 0.9, 0.1, 0.2, 0.3, 1.0], "mask": [True] * 6 + [False]}
+    stats = {"libero_spatial_no_noops": {"action": astats, "proprio": pstats}}
+    vla = modeling.OpenVLAForActionPrediction(cfg, sd, device=dev, norm_stats=stats)
+    sub = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}  # noqa: E731
+    head = modeling.L1RegressionActionHead(cfg.llm_dim, cfg.llm_dim, 7, device=dev, state_dict=sub("action_head."))
+    pp = modeling.ProprioProjector(cfg.llm_dim, 8, device=dev, state_dict=sub("proprio_projector."))
+    task = str(g["task_description"])
+    obs = {"full_image": g["full_image"].copy(), "wrist_image": g["wrist_image"].copy(), "state": g["state"].copy(), "task_description": task}
+    tok = lambda text: [1] + [3 + (7 * ord(c) + 13 * i) % 31000 for i, c in enumerate(text)][:40]  # noqa: E731  (no tokenizer files offline)
+    rcfg = types.SimpleNamespace(num_images_in_input=2, use_proprio=True, center_crop=True, unnorm_key="libero_spatial_no_noops", num_open_loop_steps=8)
+    actions = utils.get_vla_action(rcfg, vla, utils.PrismaticProcessor(tok), obs, task, action_head=head, proprio_projector=pp)
+    assert len(actions) == 8 and all(a.shape == (7,) for a in actions)
+    # the oracle on the same arrays
+    crops = [vo.crop_and_resize_center(g[k]) for k in ("full_image", "wrist_image")]
+    pv = torch.cat([vo.image_transform(c, (vo.IMAGENET_MEAN, vo.SIGLIP_MEAN), (vo.IMAGENET_STD, vo.SIGLIP_STD)) for c in crops], 0)[None].to(BF).float()
+    assert torch.equal(utils.device_pixel_values([g["full_image"], g["wrist_image"]], rcfg).float().cpu(), pv), "device image path == oracle crop + transform, bit for bit"
+    prop = vo.normalize_proprio(g["state"], pstats, "bounds_q99")
+    assert np.allclose(obs["state"], prop), "get_vla_action normalises obs['state'] in place (openvla_utils.py:773)"
+    ids = torch.tensor([tok(vo.build_prompt(task))])
+    refs = {m: vo.Oracle(ocfg, sd, mode=m).predict_action(ids, torch.ones_like(ids, dtype=torch.bool), pv, proprio=prop, unnorm_stats=astats)[0] for m in ("fp32", "bf16")}
+    got = np.stack(actions)
+    scale = np.where(astats["mask"], 0.5 * (np.array(astats["q99"]) - np.array(astats["q01"])), 1.0)      # un-normalisation stretches each dimension
+    e_hip, e_emu = np.abs((got - refs["fp32"]) / scale).max(), np.abs((refs["bf16"] - refs["fp32"]) / scale).max()
+    print(f"G13 reference observation: actions (normalised units) L-inf hip-fp32 {e_hip:.3e}, emu-fp32 {e_emu:.3e}; gripper {got[:, 6].round(3)}")
+    assert e_hip <= 1.5 * e_emu + 2 * 2.0 ** -6

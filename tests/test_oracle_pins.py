@@ -221,3 +221,32 @@ def test_jpeg_roundtrip_oracle_reproduces_libjpeg_turbo():
                 assert got.dtype == np.uint8 and np.array_equal(got, g[key]), f"{key}: {int((got != g[key]).sum())} bytes differ from libjpeg-turbo"
     ql, qc = jo.quant_tables(95)
     assert ql[0] == 2 and qc[0] == 2 and ql[63] == 10 and int(ql.min()) == 1
+
+
+def test_g13_config0_on_the_reference_observation():
+    """BASELINE.json configs[0]: `get_vla_action` on the reference's own fixture, experiments/robot/libero/sample_libero_spatial_observation.pkl,
+    CPU float32, one chunk.  The observation was extracted from the pickle WITHOUT unpickling (tests/golden/extract_libero_observation.py walks
+    the opcodes); here the oracle runs the reference plumbing on it: prompt from the task description (openvla_utils.py:753), center crop of both
+    224 x 224 frames (:542-622), dual normalisation into 12 channels (processing_prismatic.py:128-145), proprio normalisation of the 8-d state
+    (:645-675), one chunk through the tiny fp32 model, un-normalisation (modeling_prismatic.py:772-791)."""
+    import hashlib
+
+    g = load("g13_libero_observation.npz")
+    assert hashlib.sha256(g["full_image"].tobytes()).hexdigest()[:16] == "4c2183d66d17204d" and hashlib.sha256(g["wrist_image"].tobytes()).hexdigest()[:16] == "9a8866c682d1f860"
+    assert g["full_image"].shape == g["wrist_image"].shape == (224, 224, 3) and g["state"].shape == (8,) and g["state"].dtype == np.float64
+    task = str(g["task_description"])
+    assert vo.build_prompt(task) == "In: What action should the robot take to pick up the black bowl between the plate and the ramekin and place it on the plate?\nOut:"
+    ocfg, sd, _ = _tiny()
+    crops = [vo.crop_and_resize_center(g[k]) for k in ("full_image", "wrist_image")]
+    pv = torch.cat([vo.image_transform(c, (vo.IMAGENET_MEAN, vo.SIGLIP_MEAN), (vo.IMAGENET_STD, vo.SIGLIP_STD)) for c in crops], 0)[None]
+    assert pv.shape == (1, 12, 224, 224) and torch.isfinite(pv).all()
+    # LIBERO proprio = eef position | axis-angle | gripper qpos: real magnitudes (z 1.17 m, |rotation| 3.14) need real statistics
+    pstats = {"q01": [-0.5, -0.4, 0.8, 2.5, -0.5, -0.5, 0.0, -0.05], "q99": [0.3, 0.4, 1.4, 3.6, 0.5, 0.3, 0.05, 0.0]}
+    prop = vo.normalize_proprio(g["state"], pstats, ocfg.norm_type)
+    assert prop.shape == (8,) and np.all(np.abs(prop) <= 1.0) and np.abs(prop).max() > 0.05
+    rng = np.random.default_rng(13)
+    ids = torch.tensor([[1] + rng.integers(3, 31743, 36).tolist() + [29871]])      # no tokenizer files offline: seeded ids of the prompt's length class
+    stats = {"q01": [-1.0] * 7, "q99": [1.0] * 7, "mask": [True] * 6 + [False]}
+    a1, _ = vo.Oracle(ocfg, sd).predict_action(ids, torch.ones_like(ids, dtype=torch.bool), pv[:, :, ::4, ::4].contiguous(), proprio=prop, unnorm_stats=stats)
+    a2, _ = vo.Oracle(ocfg, sd).predict_action(ids, torch.ones_like(ids, dtype=torch.bool), pv[:, :, ::4, ::4].contiguous(), proprio=prop, unnorm_stats=stats)
+    assert np.asarray(a1).shape == (8, 7) and np.all(np.isfinite(a1)) and np.array_equal(a1, a2)
