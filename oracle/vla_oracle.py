@@ -9,8 +9,12 @@ Pinning status (see DESIGN.md "Oracle"):
     modules imported by path in this container (tests/golden/make_golden.py -> tests/golden/*.npz);
   * Llama decoder stack: pinned against stock transformers 5.15 LlamaForCausalLM (the reference's fork
     moojink/transformers-openvla-oft 4.40.1 is absent: bidirectional attention itself is PARITY UNPINNED);
-  * ViT blocks (timm 0.9.10 absent), LoRA (peft 0.11.1 absent), DDIM (diffusers absent): PARITY UNPINNED, restated from
-    the reference call sites and the libraries' published algorithms.
+  * ViT blocks: timm 0.9.10 is absent; `vit_block` is pinned against transformers' Dinov2Layer / SiglipEncoderLayer (independent
+    implementations of the two tower architectures, G14); the tower wrapper (patch embed, prefix tokens, "block depth-2, no final norm") is
+    restated from the reference call sites: PARITY UNPINNED against timm itself;
+  * LoRA: pinned against plain torch autograd (G8); peft 0.11.1 itself absent.  DDIM (diffusers absent): PARITY UNPINNED, restated from the
+    library's published algorithm;
+  * the JPEG round trip (oracle/jpeg_oracle.py): pinned bit-exactly against libjpeg-turbo (G12).
 
 Every function cites the reference file:line (relative to the reference root) it follows.
 
@@ -328,27 +332,34 @@ class Oracle:
             toks.append(self.W(prefix + "reg_token").expand(B, -1, -1))
         if toks:
             x = torch.cat(toks + [x], dim=1)
-        H, hd = vc.heads, vc.dim // vc.heads
         for i in range(vc.depth - 1):                                                 # blocks 0 .. depth-2
-            p = f"{prefix}blocks.{i}."
-            h = F.layer_norm(x, (vc.dim,), self.W(p + "norm1.weight"), self.W(p + "norm1.bias"), vc.eps)
-            qkv = self.linear(self.R(h), p + "attn.qkv").reshape(B, -1, 3, H, hd).permute(2, 0, 3, 1, 4)
-            a = self.R(F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]))
-            a = self.linear(a.transpose(1, 2).reshape(B, -1, vc.dim), p + "attn.proj")
-            if vc.layerscale:
-                a = self.R(a * self.W(p + "ls1.scale_factor"))
-            x = self.R(x + a)
-            if film_avg is not None:                                                  # film_vit_wrapper.py:65-75
-                gamma = self.linear(film_avg, p + "scale")
-                beta = self.linear(film_avg, p + "shift")
-                x = self.R(self.R(x * self.R(1 + gamma[:, None, :])) + beta[:, None, :])
-            h = F.layer_norm(x, (vc.dim,), self.W(p + "norm2.weight"), self.W(p + "norm2.bias"), vc.eps)
-            h = self.act(self.linear(self.R(h), p + "mlp.fc1"), vc.act)
-            h = self.linear(h, p + "mlp.fc2")
-            if vc.layerscale:
-                h = self.R(h * self.W(p + "ls2.scale_factor"))
-            x = self.R(x + h)
+            x = self.vit_block(x, f"{prefix}blocks.{i}.", vc, film_avg)
         return x[:, vc.n_prefix:]
+
+    def vit_block(self, x: torch.Tensor, p: str, vc: VitConfig, film_avg: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One pre-norm transformer block of timm's VisionTransformer (timm/models/vision_transformer.py `Block`; with FiLM:
+        film_vit_wrapper.py:56-77): x += ls1(attn(norm1 x)); [x = x (1 + gamma) + beta]; x += ls2(mlp(norm2 x)).  x (B, T, dim); parameters under
+        the name prefix `p`.  Pinned by G14 against transformers' Dinov2Layer (LayerScale) and SiglipEncoderLayer, independent implementations of
+        the same two architectures (timm itself is absent)."""
+        B = x.shape[0]
+        H, hd = vc.heads, vc.dim // vc.heads
+        h = F.layer_norm(x, (vc.dim,), self.W(p + "norm1.weight"), self.W(p + "norm1.bias"), vc.eps)
+        qkv = self.linear(self.R(h), p + "attn.qkv").reshape(B, -1, 3, H, hd).permute(2, 0, 3, 1, 4)
+        a = self.R(F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]))
+        a = self.linear(a.transpose(1, 2).reshape(B, -1, vc.dim), p + "attn.proj")
+        if vc.layerscale:
+            a = self.R(a * self.W(p + "ls1.scale_factor"))
+        x = self.R(x + a)
+        if film_avg is not None:                                                      # film_vit_wrapper.py:65-75
+            gamma = self.linear(film_avg, p + "scale")
+            beta = self.linear(film_avg, p + "shift")
+            x = self.R(self.R(x * self.R(1 + gamma[:, None, :])) + beta[:, None, :])
+        h = F.layer_norm(x, (vc.dim,), self.W(p + "norm2.weight"), self.W(p + "norm2.bias"), vc.eps)
+        h = self.act(self.linear(self.R(h), p + "mlp.fc1"), vc.act)
+        h = self.linear(h, p + "mlp.fc2")
+        if vc.layerscale:
+            h = self.R(h * self.W(p + "ls2.scale_factor"))
+        return self.R(x + h)
 
     def vision_backbone(self, pixel_values: torch.Tensor, film_avg=None) -> torch.Tensor:
         """modeling_prismatic.py:186-227 (film_vit_wrapper.py:231-276 with FiLM): channels [0:3] -> featurizer (DINOv2),

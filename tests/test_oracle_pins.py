@@ -250,3 +250,16 @@ def test_g13_config0_on_the_reference_observation():
     a1, _ = vo.Oracle(ocfg, sd).predict_action(ids, torch.ones_like(ids, dtype=torch.bool), pv[:, :, ::4, ::4].contiguous(), proprio=prop, unnorm_stats=stats)
     a2, _ = vo.Oracle(ocfg, sd).predict_action(ids, torch.ones_like(ids, dtype=torch.bool), pv[:, :, ::4, ::4].contiguous(), proprio=prop, unnorm_stats=stats)
     assert np.asarray(a1).shape == (8, 7) and np.all(np.isfinite(a1)) and np.array_equal(a1, a2)
+
+
+@pytest.mark.parametrize("tag,dim,heads,hidden,layerscale,act", [("dino", 128, 2, 256, True, "gelu"), ("siglip", 144, 2, 536, False, "gelu"),
+                                                                 ("siglip_tanh", 144, 2, 536, False, "gelu_tanh")])
+def test_g14_vit_block_matches_transformers(tag, dim, heads, hidden, layerscale, act):
+    """G14: Oracle.vit_block against transformers' Dinov2Layer (LayerScale, head_dim 64) and SiglipEncoderLayer (head_dim 72, MLP width 536, exact and
+    tanh GELU) -- independent implementations of the two tower architectures (timm, which the reference calls, is absent).  fp32, <= 2e-5."""
+    g = load("g14_hf_vit_blocks.npz")
+    sd = {"b." + k[len(tag) + 2:]: torch.from_numpy(g[k]) for k in list(g) if k.startswith(tag + "__") and not k.endswith(("__x", "__y"))}
+    vc = vo.VitConfig(dim, 3, heads, hidden, layerscale=layerscale, act=act)
+    got = vo.Oracle(vo.tiny_config(), sd).vit_block(torch.from_numpy(g[tag + "__x"]), "b.", vc)
+    err = (got - torch.from_numpy(g[tag + "__y"])).abs().max().item()
+    assert err < 2e-5, err
