@@ -36,6 +36,7 @@ struct AttnParams {
   int B, H, S, hd, causal;
   float scale;
   const bf16_bits *rope_cos, *rope_sin;   // optional: inverse RoPE fused into the dQ / dK epilogues
+  int xcd_map;                             // 1-D grids: remap the linear block id so that one (batch, head)'s blocks share an XCD
 };
 
 OVLA_DEV bf16x4_bits lds_tr16(const bf16_bits* p) {
@@ -61,6 +62,16 @@ OVLA_DEV bf16x8_bits zero8() { return bf16x8_bits{0, 0, 0, 0, 0, 0, 0, 0}; }
 OVLA_DEV bf16x8_bits gload8(const bf16_bits* base, int64_t stride, int row, int col, int hd) {
   if (col >= hd) return zero8();
   return *reinterpret_cast<const bf16x8_bits*>(base + (int64_t)row * stride + col);
+}
+
+// branch-free form (a branch around a load makes the compiler drain vmcnt at the next block boundary): head_dim == DP needs no column test;
+// the padded SigLIP case (72 of 96) loads a clamped column and zeroes the fragment afterwards
+template <int DP>
+OVLA_DEV bf16x8_bits gload8_nb(const bf16_bits* base, int64_t stride, int row, int col, int hd) {
+  if constexpr (DP != 96) return *reinterpret_cast<const bf16x8_bits*>(base + (int64_t)row * stride + col);
+  const bool in = col < hd;
+  const bf16x8_bits v = *reinterpret_cast<const bf16x8_bits*>(base + (int64_t)row * stride + (in ? col : 0));
+  return in ? v : zero8();
 }
 
 template <int DP, int NTHREADS = 256>
@@ -91,6 +102,14 @@ struct TileStage {
 };
 
 OVLA_DEV short f2bf_s(float f) { return (short)f2bf(f); }
+
+// Workgroups are handed to the 8 XCDs round-robin by linear id.  The blocks of one (batch, head) read the same K / V (or Q / dO) rows, so
+// they should meet in ONE XCD's L2: linear id n runs on XCD n % 8 and becomes work item (n % 8) * (total / 8) + n / 8, which gives every
+// XCD a contiguous run of work items (the total % 8 trailing ids keep their own index).
+OVLA_DEV int xcd_contiguous(int n, int total) {
+  const int per = total >> 3;
+  return n < 8 * per ? (n & 7) * per + (n >> 3) : n;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 template <int DP, int NW>
@@ -243,6 +262,221 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Forward, 32 query rows per wave on mfma_f32_32x32x16_bf16 (round 2).  Same transposed-score idea as above at twice the rows per
+// wave: every K / V fragment read from LDS now feeds 32 query rows, so the LDS array is busy half as long per FLOP (at 16 rows per
+// wave it was as busy as the matrix pipe).  S^T = K . Q^T leaves accS[kb][r] = S[q = lane & 31][key = 32 kb + crow(r, hi)] with
+// crow(r, hi) = (r & 3) + 8 (r >> 2) + 4 hi, hi = lane >> 5: a lane owns 16 of a key block's 32 scores of ITS query row, so the row
+// statistics need one cross-half exchange.  P feeds the second product straight from the accumulators: MFMA step t of key block kb
+// takes registers 8t .. 8t+7, i.e. contraction slot (h, j) = key 32 kb + 16 t + 8 (j >> 2) + 4 h + (j & 3), and V^T is read
+// transposed from the row-major tile in that same order (two ds_read_b64_tr_b16 per fragment).  K rows are padded to DP + 8
+// elements (conflict-free ds_read_b128 for the 32-row operand), V rows to a stride of 64 mod 128 bytes (conflict-free transposed
+// reads); both from the bank rules in MI355X_MICROARCH.md, checked by tools/lds_bank_sim.py.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int DP> struct Fwd32Cfg {
+  static constexpr int KSTR = DP + 8;
+  static constexpr int VSTR = (DP == 96) ? DP : DP + 32;
+};
+
+template <int DP, int STRIDE, int NTHREADS>
+struct TileStageS {
+  static constexpr int CH = DP / 8;
+  static constexpr int TOTAL = BKV * CH;
+  static_assert(TOTAL % NTHREADS == 0, "tile chunks must divide over the workgroup");
+  static constexpr int PER_THREAD = TOTAL / NTHREADS;
+  bf16x8_bits r[PER_THREAD];
+  OVLA_DEV void load(const bf16_bits* base, int64_t stride, int row0, int row_last, int hd, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int id = tid + NTHREADS * i;
+      const int rr = id / CH, ch = id % CH;
+      int gr = row0 + rr;
+      gr = gr < row_last ? gr : row_last;
+      r[i] = gload8_nb<DP>(base, stride, gr, ch * 8, hd);
+    }
+  }
+  OVLA_DEV void store(bf16_bits* tile, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int id = tid + NTHREADS * i;
+      const int rr = id / CH, ch = id % CH;
+      *reinterpret_cast<bf16x8_bits*>(tile + rr * STRIDE + ch * 8) = r[i];
+    }
+  }
+};
+
+// V^T fragment for one 32x32x16 step: lane (d = lane & 31, h) gets V[row0 + 4h + jj][col0 + d] (jj < 4) and V[row0 + 8 + 4h + jj][col0 + d]
+OVLA_DEV bf16x8_bits tr_frag32(const bf16_bits* tile, int row0, int col0, int stride, int lane) {
+  const int h = lane >> 5, g4 = (lane >> 4) & 1, i = lane & 15;
+  const bf16_bits* a0 = tile + (row0 + 4 * h + (i >> 2)) * stride + col0 + 16 * g4 + 4 * (i & 3);
+  const bf16x4_bits lo = lds_tr16(a0);
+  const bf16x4_bits hi = lds_tr16(a0 + 8 * stride);
+  return bf16x8_bits{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int DP>
+__global__ __launch_bounds__(256, 2) void attn_fwd32_kernel(const AttnParams p) {
+  constexpr int KS = DP / 16;   // 32x32x16 contraction steps over head_dim
+  constexpr int DB = DP / 32;   // 32-wide output blocks
+  constexpr int KSTR = Fwd32Cfg<DP>::KSTR, VSTR = Fwd32Cfg<DP>::VSTR;
+  constexpr int BQW = 128;      // 4 waves x 32 query rows
+  __shared__ __attribute__((aligned(16))) bf16_bits Ks[2][BKV * KSTR];
+  __shared__ __attribute__((aligned(16))) bf16_bits Vs[2][BKV * VSTR];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int nqb = (p.S + BQW - 1) / BQW;
+  const int wi = p.xcd_map ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const int bh = wi / nqb, b = bh / p.H, h = bh - b * p.H, q0 = (wi - bh * nqb) * BQW;
+  const int qrow = q0 + wave * 32 + (lane & 31);
+  const int qrow_c = qrow < p.S ? qrow : p.S - 1;
+  const int kvlen = p.kv_len ? p.kv_len[b] : p.S;
+  int kv_end = kvlen < p.S ? kvlen : p.S;
+  if (p.causal) kv_end = kv_end < (q0 + BQW) ? kv_end : (q0 + BQW);
+  const int ntiles = (kv_end + BKV - 1) / BKV;
+
+  const bf16_bits* Qb = p.Q + (int64_t)b * p.S * p.q_stride + (int64_t)h * p.hd;
+  const bf16_bits* Kb = p.K + (int64_t)b * p.S * p.k_stride + (int64_t)h * p.hd;
+  const bf16_bits* Vb = p.V + (int64_t)b * p.S * p.v_stride + (int64_t)h * p.hd;
+
+  bf16x8_bits qf[KS];   // B operand of S^T = K . Q^T: B[k = 8 hi + j][col = q] = Q[q][16 s + 8 hi + j]
+#pragma unroll
+  for (int s = 0; s < KS; ++s) qf[s] = gload8_nb<DP>(Qb, p.q_stride, qrow_c, 16 * s + 8 * hi, p.hd);
+
+  f32x16 accO[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accO[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;   // m_run: running max of the RAW scores (the positive scale is applied inside the exp2 fma)
+  const float sl2 = p.scale * LOG2E;
+
+  TileStageS<DP, KSTR, 256> kst;
+  TileStageS<DP, VSTR, 256> vst;
+  if (ntiles > 0) {
+    kst.load(Kb, p.k_stride, 0, p.S - 1, p.hd, tid);
+    vst.load(Vb, p.v_stride, 0, p.S - 1, p.hd, tid);
+    kst.store(Ks[0], tid);
+    vst.store(Vs[0], tid);
+  }
+  __syncthreads();
+
+  // Tile t + 1 is fetched into registers at the top of iteration t and written to the other LDS buffer at its bottom: the loads are in flight
+  // under the whole tile's math and are waited for inside the iteration that issued them.  (Measured the same as the 16-row kernels' order,
+  // fetch of tile t + 2 at the bottom of iteration t; this one needs no second prologue fetch.)
+  auto tile = [&](int t, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    const bf16_bits* Kt = Ks[t & 1];
+    const bf16_bits* Vt = Vs[t & 1];
+    // (rows beyond the context clamp to the last row: harmless re-reads, masked in the last tile)
+    kst.load(Kb, p.k_stride, (t + 1) * BKV, p.S - 1, p.hd, tid);
+    vst.load(Vb, p.v_stride, (t + 1) * BKV, p.S - 1, p.hd, tid);
+    f32x16 accS[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accS[kb][r] = 0.f;
+    {
+      // K fragments are read HALF a key block (KS / 2 fragments) ahead of the MFMAs that consume them: two register sets, the reads of
+      // the next half issued before the MFMAs of the current one (left to itself the compiler reads two fragments, waits, issues two MFMAs)
+      constexpr int HS = KS / 2;
+      const bf16_bits* krow = Kt + (lane & 31) * KSTR + 8 * hi;
+      bf16x8_bits ka[HS], kb_[HS];
+#pragma unroll
+      for (int s = 0; s < HS; ++s) ka[s] = *reinterpret_cast<const bf16x8_bits*>(krow + 16 * s);
+#pragma unroll
+      for (int s = 0; s < HS; ++s) kb_[s] = *reinterpret_cast<const bf16x8_bits*>(krow + 16 * (HS + s));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < HS; ++s) accS[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s], qf[s], accS[0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < HS; ++s) ka[s] = *reinterpret_cast<const bf16x8_bits*>(krow + 32 * KSTR + 16 * s);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < HS; ++s) accS[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_[s], qf[HS + s], accS[0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < HS; ++s) kb_[s] = *reinterpret_cast<const bf16x8_bits*>(krow + 32 * KSTR + 16 * (HS + s));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < HS; ++s) accS[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s], qf[s], accS[1], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < HS; ++s) accS[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb_[s], qf[HS + s], accS[1], 0, 0, 0);
+    }
+    const int kbase = t * BKV;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if constexpr (MASK) {
+          const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const bool ok = key < kvlen && (!p.causal || key <= qrow);
+          accS[kb][r] = ok ? accS[kb][r] : -INFINITY;
+        }
+        mx = fmaxf(mx, accS[kb][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_safe) * sl2);
+    const float moff = -m_safe * sl2;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(accS[kb][r], sl2, moff));
+        accS[kb][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accO[d][r] *= alpha;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        bf16x8_bits pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = f2bf_s(accS[kb][8 * tt + j]);
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+          accO[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag32(Vt, kb * 32 + 16 * tt, d * 32, VSTR, lane), pf, accO[d], 0, 0, 0);
+      }
+    kst.store(Ks[(t + 1) & 1], tid);
+    vst.store(Vs[(t + 1) & 1], tid);
+    __syncthreads();
+  };
+  int n_free = kvlen / BKV;
+  if (p.causal) n_free = n_free < (q0 / BKV) ? n_free : (q0 / BKV);
+  if (n_free > ntiles) n_free = ntiles;
+  for (int t = 0; t < n_free; ++t) tile(t, std::false_type{});
+  for (int t = n_free; t < ntiles; ++t) tile(t, std::true_type{});
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv_l = l_run > 0.f ? 1.0f / l_run : 0.f;
+  if (qrow < p.S) {
+    bf16_bits* Ob = p.Oout + ((int64_t)b * p.S + qrow) * p.o_stride + (int64_t)h * p.hd;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int col = d * 32 + 8 * rq + 4 * hi;
+        if (col < p.hd) {
+          bf16x4_bits o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = f2bf_s(accO[d][4 * rq + j] * inv_l);
+          *reinterpret_cast<bf16x4_bits*>(Ob + col) = o;
+        }
+      }
+    if (hi == 0 && p.lse) p.lse[((int64_t)b * p.H + h) * p.S + qrow] = m_run * sl2 * LN2 + __logf(l_run);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // dQ: one workgroup per 64-query block, loops over K/V tiles.
 // Inverse RoPE (HF rotate_half convention) on one row's gradient held as DT = hd/16 accumulator tiles: lane (row = lane & 15,
 // g = lane >> 4) owns columns 16 d + 4 g + j; the rotation partner of column c is c +- hd/2 = tile d +- DT/2, same lane.  Values are
@@ -269,8 +503,8 @@ OVLA_DEV void inverse_rope_store(const f32x4 (&acc)[DT], float scale, bf16_bits*
   }
 }
 
-template <int DP, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParams p) {
+template <int DP, int NW, int OCC = 2, bool BATCH = (DP == 128)>
+__global__ __launch_bounds__(64 * NW, OCC) void attn_bwd_dq_kernel(const AttnParams p) {
   constexpr int KS = DP / 32, DT = DP / 16, STRIDE = DP + 16;
   constexpr int NTH = 64 * NW;
   constexpr int BQW = 16 * NW;   // query rows per workgroup (NW = 8: 128 rows share every K / V tile)
@@ -278,7 +512,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParam
   __shared__ __attribute__((aligned(16))) bf16_bits Ks[2][BKV * STRIDE];
   __shared__ __attribute__((aligned(16))) bf16_bits Vs[2][BKV * STRIDE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQW;
+  int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * BQW;
+  if (p.xcd_map) {   // 1-D grid: the query blocks of one (batch, head) run on one XCD and share its L2 copy of K / V
+    const int nqb = (p.S + BQW - 1) / BQW;
+    const int wi = xcd_contiguous(blockIdx.x, gridDim.x), bh = wi / nqb;
+    b = bh / p.H; h = bh - b * p.H; q0 = (wi - bh * nqb) * BQW;
+  }
   const int qrow = q0 + wave * 16 + (lane & 15);
   const int qrow_c = qrow < p.S ? qrow : p.S - 1;
   const int kvlen = p.kv_len ? p.kv_len[b] : p.S;
@@ -341,6 +580,32 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParam
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       f32x4 accS[2], accP[2];
+      if constexpr (BATCH) {
+        // all K / V row fragments of this half are read first, then the 4 KS MFMAs run back to back (left alone the compiler reads one or two
+        // fragments, waits for them, issues one or two 16-cycle MFMAs: an LDS round trip every other MFMA)
+        bf16x8_bits kfr[2][KS], vfr[2][KS];
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            kfr[nn][s] = row_frag(Kt, (2 * s2 + nn) * 16 + (lane & 15), 32 * s + 8 * g, STRIDE);
+            vfr[nn][s] = row_frag(Vt, (2 * s2 + nn) * 16 + (lane & 15), 32 * s + 8 * g, STRIDE);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nn = 0; nn < 2; ++nn) {
+          accS[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+          accP[nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int nn = 0; nn < 2; ++nn) {
+            accS[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[nn][s], qf[s], accS[nn], 0, 0, 0);
+            accP[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[nn][s], dof[s], accP[nn], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
 #pragma unroll
       for (int nn = 0; nn < 2; ++nn) {
         const int nt = 2 * s2 + nn;
@@ -351,6 +616,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParam
           accS[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Kt, nt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), qf[s], accS[nn], 0, 0, 0);
           accP[nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vt, nt * 16 + (lane & 15), 32 * s + 8 * g, STRIDE), dof[s], accP[nn], 0, 0, 0);
         }
+      }
       }
       bf16x8_bits dsf;
 #pragma unroll
@@ -365,9 +631,18 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq_kernel(const AttnParam
           }
           dsf[4 * nn + j] = f2bf_s(pv * (accP[nn][j] - Dq));   // dS (unscaled)
         }
+      if constexpr (BATCH) {
+        bf16x8_bits ktr[DT];
+#pragma unroll
+        for (int d = 0; d < DT; ++d) ktr[d] = tr_frag(Kt, 32 * s2, d * 16, STRIDE, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) accQ[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktr[d], dsf, accQ[d], 0, 0, 0);
+      } else {
 #pragma unroll
       for (int d = 0; d < DT; ++d)
         accQ[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Kt, 32 * s2, d * 16, STRIDE, lane), dsf, accQ[d], 0, 0, 0);
+      }
     }
     if (t + 1 < ntiles) {   // tile t+1 (in registers since the previous iteration) -> the other LDS buffer; fetch tile t+2
       kst.store(Ks[(t + 1) & 1], tid);
@@ -416,7 +691,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dkv_kernel(const AttnPara
   __shared__ __attribute__((aligned(16))) bf16_bits dOs[2][BQ * STRIDE];
   __shared__ float Ls[2][BQ], Ds[2][BQ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * BKW;
+  int b = blockIdx.z, h = blockIdx.y, k0 = blockIdx.x * BKW;
+  if (p.xcd_map) {   // 1-D grid: the key blocks of one (batch, head) run on one XCD and share its L2 copy of Q / dO
+    const int nkb = (p.S + BKW - 1) / BKW;
+    const int wi = xcd_contiguous(blockIdx.x, gridDim.x), bh = wi / nkb;
+    b = bh / p.H; h = bh - b * p.H; k0 = (wi - bh * nkb) * BKW;
+  }
   const int krow = k0 + wave * 16 + (lane & 15);
   const int krow_c = krow < p.S ? krow : p.S - 1;
   const int kvlen = p.kv_len ? p.kv_len[b] : p.S;
@@ -586,7 +866,17 @@ extern "C" int ovla_attn_fwd(const ovla_attn_fwd_args* a, void* stream_) {
   p.Q = (const bf16_bits*)a->Q; p.K = (const bf16_bits*)a->K; p.V = (const bf16_bits*)a->V; p.Oout = (bf16_bits*)a->O;
   p.q_stride = a->q_stride; p.k_stride = a->k_stride; p.v_stride = a->v_stride; p.o_stride = a->o_stride;
   p.lse = a->lse; p.kv_len = a->kv_len; p.B = a->B; p.H = a->H; p.S = a->S; p.hd = a->head_dim; p.causal = a->causal; p.scale = a->scale;
-  if (a->S > 64) {   // 8 waves x 16 query rows = 128 rows per workgroup share every K/V tile
+  static const bool fwd32 = []() { const char* e = getenv("OVLA_ATTN_FWD32"); return !(e && e[0] == '0'); }();   // A/B switch
+  static const bool xcd_map = []() { const char* e = getenv("OVLA_ATTN_XCD"); return !(e && e[0] == '0'); }();   // A/B switch
+  p.xcd_map = xcd_map ? 1 : 0;
+  if (fwd32 && a->S > 64) {   // 4 waves x 32 query rows on the 32x32x16 MFMA
+    const dim3 grid((unsigned)(cdiv(a->S, 128) * a->H * a->B));
+    switch (a->head_dim) {
+      case 64: hipLaunchKernelGGL((attn_fwd32_kernel<64>), grid, dim3(256), 0, stream, p); break;
+      case 72: hipLaunchKernelGGL((attn_fwd32_kernel<96>), grid, dim3(256), 0, stream, p); break;
+      default: hipLaunchKernelGGL((attn_fwd32_kernel<128>), grid, dim3(256), 0, stream, p); break;
+    }
+  } else if (a->S > 64) {   // 8 waves x 16 query rows = 128 rows per workgroup share every K/V tile
     const dim3 grid(cdiv(a->S, 128), a->H, a->B);
     switch (a->head_dim) {
       case 64: hipLaunchKernelGGL((attn_fwd_kernel<64, 8>), grid, dim3(512), 0, stream, p); break;
@@ -624,8 +914,11 @@ extern "C" int ovla_attn_bwd(const ovla_attn_bwd_args* a, void* stream_) {
   p.lse_in = a->lse; p.delta = a->delta; p.kv_len = a->kv_len;
   p.B = a->B; p.H = a->H; p.S = a->S; p.hd = a->head_dim; p.causal = a->causal; p.scale = a->scale;
   p.rope_cos = (const bf16_bits*)a->rope_cos; p.rope_sin = (const bf16_bits*)a->rope_sin;
-  const dim3 grid(cdiv(a->S, BQ), a->H, a->B);
-  const dim3 grid_kv4(cdiv(a->S, 64), a->H, a->B), grid_kv8(cdiv(a->S, 128), a->H, a->B);
+  static const bool xcd_map = []() { const char* e = getenv("OVLA_ATTN_XCD"); return !(e && e[0] == '0'); }();   // A/B switch
+  p.xcd_map = xcd_map ? 1 : 0;
+  const dim3 grid = xcd_map ? dim3((unsigned)(cdiv(a->S, BQ) * a->H * a->B)) : dim3(cdiv(a->S, BQ), a->H, a->B);
+  const dim3 grid_kv4 = grid;
+  const dim3 grid_kv8 = xcd_map ? dim3((unsigned)(cdiv(a->S, 128) * a->H * a->B)) : dim3(cdiv(a->S, 128), a->H, a->B);
   switch (a->head_dim) {
     case 64:
       hipLaunchKernelGGL((attn_bwd_dq_kernel<64, 4>), grid, dim3(256), 0, stream, p);
@@ -641,7 +934,11 @@ extern "C" int ovla_attn_bwd(const ovla_attn_bwd_args* a, void* stream_) {
       }
       break;
     default:   // the Llama shape: 8 waves = 128 keys share every Q / dO tile
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 8>), grid_kv8, dim3(512), 0, stream, p);
+      {
+        static const bool dq_batch = []() { const char* e = getenv("OVLA_ATTN_DQ_BATCH"); return !(e && e[0] == '0'); }();   // A/B switch
+        if (dq_batch) hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 8>), grid_kv8, dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((attn_bwd_dq_kernel<128, 8, 2, false>), grid_kv8, dim3(512), 0, stream, p);
+      }
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<128, 8>), grid_kv8, dim3(512), 0, stream, p);
       break;
   }

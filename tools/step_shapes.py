@@ -30,15 +30,31 @@ def traced(a, b, **kw):
     return out
 ops.gemm = traced
 engine_mod.ops.gemm = traced
+tn_records = []
+orig_tn = ops.gemm_tn_grouped
+def traced_tn(problems):
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(); orig_tn(problems); e1.record()
+    tn_records.append((tuple((x.shape[0], x.shape[1], y.shape[1]) for x, y, _ in problems), e0, e1))
+ops.gemm_tn_grouped = traced_tn
+engine_mod.ops.gemm_tn_grouped = traced_tn
 step(); torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0.0])
 for key, e0, e1 in records:
     agg[key][0] += 1; agg[key][1] += e0.elapsed_time(e1)
 tot = sum(v[1] for v in agg.values())
 print(f"total gemm_nt ms {tot:.1f}, launches {len(records)}")
-print(f"{'M':>6} {'N':>6} {'K':>6} {'K2':>4} {'grp':>4} {'n':>5} {'ms':>8} {'us/launch':>10} {'TF':>6}")
+print(f"{'M':>6} {'N':>6} {'K':>6} {'K2':>4} {'grp':>4} {'n':>5} {'ms':>8} {'us/launch':>10} {'TF':>6} {'GB/s':>6}")
 for key, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     M, N, K, K2, g = key
     G = (N // g) if g else 1
     fl = 2.0 * M * N * (K + K2)
-    print(f"{M:6d} {N:6d} {K:6d} {K2:4d} {g:4d} {n:5d} {ms:8.2f} {1e3 * ms / n:10.1f} {fl * n / ms / 1e9:6.0f}")
+    by = 2.0 * (M * K + N * K + M * N + (M + N) * K2)
+    print(f"{M:6d} {N:6d} {K:6d} {K2:4d} {g:4d} {n:5d} {ms:8.2f} {1e3 * ms / n:10.1f} {fl * n / ms / 1e9:6.0f} {by * n / ms / 1e6:6.0f}")
+agg = collections.defaultdict(lambda: [0, 0.0])
+for key, e0, e1 in tn_records:
+    agg[key][0] += 1; agg[key][1] += e0.elapsed_time(e1)
+print(f"total gemm_tn_grouped ms {sum(v[1] for v in agg.values()):.1f}, launches {len(tn_records)}")
+for key, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    by = sum(2.0 * M * (P + Q) + 4.0 * P * Q for M, P, Q in key)
+    print(f"{str(key):90s} {n:4d} {ms:7.2f} ms {1e3 * ms / n:7.1f} us {by * n / ms / 1e6:6.0f} GB/s")
