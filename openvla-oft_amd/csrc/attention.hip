@@ -15,6 +15,9 @@
 // K/V (or Q/dO) tiles are register-staged (global_load_dwordx4 issued one tile ahead, written to LDS after the barrier)
 // into rows of head_dim_padded + 16 elements: that stride makes both the ds_read_b128 row reads and the transposed
 // reads bank-conflict free for head_dim 128.
+// The forward for contexts > 64 tokens is attn_fwd32_kernel further down: the same scheme at 32 query rows per wave on
+// mfma_f32_32x32x16_bf16 (its own LDS strides).  Every kernel on a 1-D grid maps its linear block id so that the blocks of
+// one (batch, head) run on one XCD (xcd_contiguous).  Measurements and what bounds these kernels: profiles/r02_attn_pmc.md.
 #include "common.h"
 #include <type_traits>
 

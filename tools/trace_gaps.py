@@ -1,5 +1,7 @@
 """GPU idle time inside the timed steps of a bench run, from a rocprofv3 --kernel-trace CSV: union of the kernels' busy
-intervals vs wall time, and the idle gaps grouped by the kernel that FOLLOWS them (who was the GPU waiting for)."""
+intervals vs wall time, and the idle gaps grouped by the kernel that FOLLOWS them (who was the GPU waiting for).
+Caveat: under rocprofv3 every launch costs the host ~10 us more, which makes the ~3500-launch step host-bound (21 % idle in the trace);
+without the profiler the host enqueues a step in 39 ms against 169 ms of GPU time (tools/enqueue_time.py), so read the gaps as an upper bound."""
 import csv, sys, collections
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
