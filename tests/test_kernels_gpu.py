@@ -253,6 +253,15 @@ ATTN_CASES = [
     (2, 2, 200, 128, None, True),
     (2, 2, 333, 128, [333, 100], True),
     (1, 2, 50, 72, None, False),
+    # round 2: the 32-row forward and the XCD-contiguous block order (block counts that are not multiples of 8, one-block grids,
+    # key padding that ends on / inside / before the first tile, the ALOHA context, causal diagonals inside the 128-row blocks)
+    (1, 3, 65, 128, None, False),
+    (3, 5, 130, 64, [130, 64, 1], False),
+    (2, 3, 129, 72, [129, 77], True),
+    (1, 2, 1159, 128, [1100], False),
+    (2, 2, 200, 128, [128, 192], False),
+    (1, 3, 608, 128, None, True),
+    (5, 1, 96, 64, None, True),
 ]
 
 
