@@ -39,6 +39,7 @@ _FUSE = os.environ.get("OVLA_FUSE_DACT", "none")
 # traffic beyond one more slab read, no barrier) -- see DESIGN.md section 6 for the A/B.  OVLA_FUSE_ROPE_FWD=0 restores the separate pass.
 # The INVERSE RoPE of the backward, which needs no loads beyond the tables and no LDS (attention-backward epilogue), is on: -0.6 ms.
 _FUSE_ROPE_FWD = os.environ.get("OVLA_FUSE_ROPE_FWD", "1") == "1"
+_GROUP_TN = os.environ.get("OVLA_GROUP_TN", "1") == "1"   # ViT blocks: two neighbouring linears' LoRA weight-gradient problems in one launch (A/B switch)
 _FUSE_ACT, _FUSE_SWIGLU = _FUSE in ("act", "all"), _FUSE in ("swiglu", "all")
 # The action head's tail (two MLPResNet blocks, LayerNorm 2, fc2, L1 / MSE loss) as ONE launch for up to 64 rows (ovla_head_tail_fwd),
 # bit-identical to the unfused eight-launch sequence, so the switch is invisible in the numbers.  Measured: at 64 rows
@@ -214,10 +215,12 @@ class LoraLinear:
             y = ops.gemm(x, self.W, out=out, bias=self.bias, act=act, residual=residual, colscale=colscale, c_pre=c_pre, film=film, rope=rope)
         return y, (x, t_s)
 
-    def bwd(self, dy, saved, need_dx=True, dact=None):
+    def bwd(self, dy, saved, need_dx=True, dact=None, tn_queue=None):
         """dy [M, out] (gradient w.r.t. the pre-activation linear output) -> dx [M, in]; accumulates LoRA grads.
         `dact` = ("act", z, act_id) / ("swiglu", gu): the data-gradient GEMM's epilogue also applies the derivative of the
-        activation that PRODUCED this linear's input (returns dz / d(gate|up) instead of dx: ovla.h backward epilogues)."""
+        activation that PRODUCED this linear's input (returns dz / d(gate|up) instead of dx: ovla.h backward epilogues).
+        `tn_queue`: a list that collects this linear's weight-gradient TN problems instead of launching them; the caller launches the
+        list (ops.gemm_tn_grouped) BEFORE anything overwrites `dy` -- two neighbouring linears' four small problems share one launch."""
         x, t_s = saved
         dx = None
         if getattr(self, "merged", False):
@@ -229,7 +232,10 @@ class LoraLinear:
             # dB_g += dy_g^T t_g ; dA += dt^T x : one grouped launch
             probs = [(dy[:, g * gn:(g + 1) * gn], t_s[:, g * r:(g + 1) * r], self.B.grad[g * gn:(g + 1) * gn]) for g in range(G)]
             probs.append((dt, x, self.A.grad))
-            ops.gemm_tn_grouped(probs)
+            if tn_queue is not None:
+                tn_queue.extend(probs)
+            else:
+                ops.gemm_tn_grouped(probs)
             if need_dx:
                 dx = ops.gemm(dy, self.WT, a2=dt, b2=self.AT, dact=dact)
         elif need_dx:
@@ -385,11 +391,14 @@ class VitTower:
             x, mean1, rstd1, s_qkv, qkv, o, lse, s_proj, x2, mean2, rstd2, s_fc1, z, s_fc2, fsv = sv
             # x3 = x2 + ls2 * fc2(act(fc1(ln2(x2))))
             d = ops.colscale(dx, blk["ls2"]) if blk["ls2"] is not None else dx
+            tnq = [] if _GROUP_TN else None   # fc2's and fc1's LoRA weight gradients: four ~9 MB problems in ONE launch, before norm_bwd rewrites dx
             if _FUSE_ACT:
-                dz = blk["fc2"].bwd(d, s_fc2, dact=("act", z, self.act))  # dh * act'(z) in the dgrad GEMM's epilogue
+                dz = blk["fc2"].bwd(d, s_fc2, dact=("act", z, self.act), tn_queue=tnq)  # dh * act'(z) in the dgrad GEMM's epilogue
             else:
-                dz = ops.act_bwd(z, blk["fc2"].bwd(d, s_fc2), self.act)
-            dh2 = blk["fc1"].bwd(dz, s_fc1)
+                dz = ops.act_bwd(z, blk["fc2"].bwd(d, s_fc2, tn_queue=tnq), self.act)
+            dh2 = blk["fc1"].bwd(dz, s_fc1, tn_queue=tnq)
+            if tnq:
+                ops.gemm_tn_grouped(tnq)
             ops.norm_bwd(x2, dh2, blk["ln2_w"], mean2, rstd2, rms=False, dx=dx, dx_accum=True)       # dx now = d x2
             if fsv is not None:   # through the FiLM modulation: dgamma, dbeta, dx <- dx * (1 + gamma)
                 gamma, s_sc, s_sh, xpre, frows = fsv
@@ -401,12 +410,15 @@ class VitTower:
                 blk["film"][1].bwd(ops.cvt_f32_to_bf16(db), s_sh, need_dx=False)
             # x2 = x + ls1 * proj(attn(qkv(ln1(x))))
             d = ops.colscale(dx, blk["ls1"]) if blk["ls1"] is not None else dx
-            do = blk["proj"].bwd(d, s_proj)
+            tnq = [] if _GROUP_TN else None   # likewise proj + qkv
+            do = blk["proj"].bwd(d, s_proj, tn_queue=tnq)
             dqkv = torch.empty_like(qkv)
             D = vc.dim
             ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], o, do, lse, B, T, H, hd, dq=dqkv[:, :D], dk=dqkv[:, D:2 * D],
                          dv=dqkv[:, 2 * D:])
-            dh1 = blk["qkv"].bwd(dqkv, s_qkv, need_dx=not first_block)   # block 0 still needs its LoRA gradients, not d x
+            dh1 = blk["qkv"].bwd(dqkv, s_qkv, need_dx=not first_block, tn_queue=tnq)   # block 0 still needs its LoRA gradients, not d x
+            if tnq:
+                ops.gemm_tn_grouped(tnq)
             if not first_block:
                 ops.norm_bwd(x, dh1, blk["ln1_w"], mean1, rstd1, rms=False, dx=dx, dx_accum=True)    # dx now = d x
         return None  # patch embedding / position embedding are frozen and the pixels need no gradient
