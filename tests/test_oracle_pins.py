@@ -263,3 +263,46 @@ def test_g14_vit_block_matches_transformers(tag, dim, heads, hidden, layerscale,
     got = vo.Oracle(vo.tiny_config(), sd).vit_block(torch.from_numpy(g[tag + "__x"]), "b.", vc)
     err = (got - torch.from_numpy(g[tag + "__y"])).abs().max().item()
     assert err < 2e-5, err
+
+
+def _textured_image(h, w, seed=0):
+    rng = np.random.default_rng(seed)
+    _, xx = np.mgrid[0:h, 0:w]
+    return np.stack([(127 + 100 * np.sin(xx / 17.0 + c) + 20 * rng.standard_normal((h, w))) for c in range(3)], -1).clip(0, 255).astype(np.uint8)
+
+
+def test_center_crop_bilinear_against_scipy():
+    """TensorFlow is absent, so `crop_and_resize_center` (openvla_utils.py:542-622) stays "parity unpinned" against TF itself.  This pins its
+    INTERPOLATION against an independent implementation: scipy's order-1 map_coordinates in float64 at the sample positions the TF kernel
+    documents (in = y1 (H - 1) + i (y2 - y1)(H - 1) / (out - 1)).  The two may differ by one LSB where float32 and float64 round apart."""
+    ndimage = pytest.importorskip("scipy.ndimage")
+    img = _textured_image(256, 320)
+    out = vo.crop_and_resize_center(img, 0.9, 224)
+    side = np.sqrt(0.9)
+    o1 = (1 - side) / 2
+
+    def coords(n):
+        return o1 * (n - 1) + np.arange(224) * (side * (n - 1) / 223)
+
+    cy, cx = np.meshgrid(coords(256), coords(320), indexing="ij")
+    ref = np.stack([ndimage.map_coordinates(img[..., c].astype(np.float64) / 255.0, [cy, cx], order=1, mode="nearest") for c in range(3)], -1)
+    ref_u8 = (np.clip(ref, 0, 1) * 255.5).astype(np.uint8)
+    d = np.abs(out.astype(int) - ref_u8.astype(int))
+    assert d.max() <= 1 and (d == 0).mean() >= 0.999, ((d == 0).mean(), d.max())
+
+
+@pytest.mark.parametrize("out_hw", [(224, 224), (128, 160)])
+def test_lanczos3_resize_close_to_pillow(out_hw):
+    """`resize_lanczos3` restates tf.image.resize(method="lanczos3", antialias=True) (scale_and_translate_op.cc; TF absent -> unpinned against TF).
+    Pillow's LANCZOS filter is the same kernel family (radius 3, support scaled by the shrink factor, half-pixel centres) in 8-bit fixed point with a
+    rounding step between its two passes: the two must agree to one LSB almost everywhere -- a check on the kernel definition and the sampling
+    grid, not a bit-exact pin."""
+    Image = pytest.importorskip("PIL.Image")
+    from oracle import data_oracle as do
+
+    img = _textured_image(256, 320)
+    h2, w2 = out_hw
+    mine = do.resize_lanczos3(img, h2, w2)
+    pil = np.asarray(Image.fromarray(img).resize((w2, h2), Image.LANCZOS))
+    d = np.abs(mine.astype(int) - pil.astype(int))
+    assert (d <= 1).mean() >= 0.995 and d.mean() <= 0.3 and d.max() <= 8, ((d <= 1).mean(), d.mean(), d.max())
