@@ -319,7 +319,8 @@ class Oracle:
     # -- ViT (timm VisionTransformer; call site modeling_prismatic.py:127-139, 186-227) ---------------------------------
     def vit(self, img: torch.Tensor, prefix: str, vc: VitConfig, film_avg: Optional[torch.Tensor] = None) -> torch.Tensor:
         """img (B,3,H,W) -> (B, n_patches, dim): output of block index depth-2, prefix tokens dropped, no final norm
-        (get_intermediate_layers(n={depth-2}), norm=False).  PARITY UNPINNED (timm absent)."""
+        (get_intermediate_layers(n={depth-2}), norm=False).  timm is absent; the tower-level wiring is pinned by G15 against transformers'
+        Dinov2WithRegistersModel / SiglipVisionModel `hidden_states[-2]` (independent implementations of the two architectures)."""
         B = img.shape[0]
         w = self.W(prefix + "patch_embed.proj.weight")
         x = F.conv2d(img, w, self.W(prefix + "patch_embed.proj.bias"), stride=vc.patch)

@@ -306,3 +306,18 @@ def test_lanczos3_resize_close_to_pillow(out_hw):
     pil = np.asarray(Image.fromarray(img).resize((w2, h2), Image.LANCZOS))
     d = np.abs(mine.astype(int) - pil.astype(int))
     assert (d <= 1).mean() >= 0.995 and d.mean() <= 0.3 and d.max() <= 8, ((d <= 1).mean(), d.mean(), d.max())
+
+
+@pytest.mark.parametrize("tag,vc", [("dino", vo.VitConfig(64, 3, 1, 128, n_prefix=5, layerscale=True, image_size=42)),
+                                    ("siglip", vo.VitConfig(72, 3, 1, 136, image_size=42))])
+def test_g15_tower_wiring_matches_transformers(tag, vc):
+    """G15: Oracle.vit -- patch + position embedding, [cls, 4 registers, patches] prefix, the output of block index depth - 2 with no final norm and the
+    prefix dropped -- against transformers' Dinov2WithRegistersModel / SiglipVisionModel `hidden_states[-2]` (make_golden_hf_towers.py; timm is absent).
+    fp32, <= 5e-5."""
+    g = load("g15_hf_towers.npz")
+    sd = {"t." + k[len(tag) + 2:]: torch.from_numpy(g[k]) for k in list(g) if k.startswith(tag + "__") and not k.endswith(("__x", "__y"))}
+    got = vo.Oracle(vo.tiny_config(), sd).vit(torch.from_numpy(g[tag + "__x"]), "t.", vc)
+    want = torch.from_numpy(g[tag + "__y"])
+    assert got.shape == want.shape
+    err = (got - want).abs().max().item()
+    assert err < 5e-5, err
