@@ -2,7 +2,9 @@
 """bench.py -- OpenVLA-OFT LoRA fine-tune step throughput on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU over RCCL)
+  N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`:
+  RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or, when WORLD_SIZE is unset, this process starts them itself as children
+  (the same torch.distributed.run command on 127.0.0.1, before anything here touches the GPU), relays rank 0's JSON line and exits with their status.
 
 Workload (config.workload): BASELINE.json configs[2] -- LoRA (rank 32) fine-tune of OpenVLA-7B on synthetic
 LIBERO-Spatial batches, bf16, batch 8 per GPU, 2 x 224x224 images + proprio, L1-regression head, S = 608.
@@ -252,6 +254,25 @@ def measured_traffic(tiny: bool):
                                      "traffic_shape_mnk": rec.get("shape"), "traffic_stale": rec.get("gemm_nt_sha16") != sha}
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes through torch.distributed.run (the command the
+    driver would type: vla-scripts/finetune.py:212-224,796 run under torchrun the same way), on 127.0.0.1 with a free port.  This parent never
+    initialises the GPU and never execs; the children's stdout / stderr pass through (rank 0 prints the JSON line), their status is returned."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    print(f"[bench] WORLD_SIZE unset: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,10 +289,14 @@ def main():
     ap.add_argument("--eager-baseline", action="store_true", help="time the stock PyTorch-ROCm eager step instead (BASELINE.md B1) and exit")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))          # no HIP call has happened in this process; the ranks are fresh children
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it as `python bench.py --gpus N`, or under "
+                         f"`torch.distributed.run --nproc-per-node N`)")
     ndev = torch.cuda.device_count()
     backend = os.environ.get("OVLA_DIST_BACKEND", "nccl")   # "gloo": rehearsal of the multi-process path on a 1-GPU box
     dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
@@ -367,6 +392,11 @@ def main():
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    n_ranks_seen = 1
+    if world > 1:    # every rank adds a one: the line below then shows how many processes really took part in the collectives
+        ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        n_ranks_seen = int(ones.item())
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.batch * args.steps / elapsed
     final_loss = loss_sum.item() / (args.batch * cfg.chunk * cfg.action_dim)
@@ -485,6 +515,7 @@ def main():
     if rank == 0:
         print(json.dumps({
             "metric": "fine-tune samples/s (action-chunks/s) OpenVLA-7B bf16", "value": value, "unit": "samples/s", "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen, "dist_backend": backend if world > 1 else None,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (seeded random weights of the OpenVLA-7B architecture, synthetic LIBERO-shaped batches)",
             "config": {"workload": ("SURVEY 8(d) config 5 [side measurement]: ALOHA shapes, 3x224x224 images + proprio 14, 25x14 chunk, FiLM + diffusion head (MSE), LoRA r=32 step" if args.aloha else

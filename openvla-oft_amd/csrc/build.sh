@@ -14,11 +14,13 @@ set -euo pipefail
 cd "$(dirname "$0")"
 MODE="${1:-product}"
 OUT=../libovla_hip.so; EXTRA=""; BUILD=../_build
-NOPK="core.hip gemm_nt.hip gemm_tn.hip attention.hip elementwise.hip head_optim.hip selftest.hip"
+# EVERY .hip file in this directory is a source of the library and gets the flag: a new file cannot silently lose the protection
+# (tests/test_host_logic.py::test_shipped_code_object_has_no_packed_fp32 disassembles the built library and fails on any v_pk_*_f32).
+SRCS="$(ls *.hip | LC_ALL=C sort | tr '\n' ' ')"
+NOPK="$SRCS"
 if [ "$MODE" = "ablate" ]; then OUT=../libovla_hip_ablate.so; EXTRA="-DOVLA_GEMM_ABLATE"; BUILD=../_build_ablate; fi
 if [ "$MODE" = "packed" ]; then OUT=../libovla_hip_packed.so; BUILD=../_build_packed; NOPK=""; fi
 NOPK_FLAGS="-Xclang -target-feature -Xclang -packed-fp32-ops"   # (the host pass prints "not a recognized feature ... ignoring": filtered below)
-SRCS="core.hip gemm_nt.hip gemm_tn.hip attention.hip elementwise.hip head_optim.hip selftest.hip"
 HASH=$(cat $(ls *.hip *.h | LC_ALL=C sort) build.sh ../../include/ovla.h | sha256sum | cut -c1-32)
 STAMP="$HASH-$MODE"
 if [ -f "$OUT" ] && [ -f "$OUT.hash" ] && [ "$(cat "$OUT.hash")" = "$STAMP" ]; then echo "$(basename $OUT) up to date ($HASH)"; exit 0; fi

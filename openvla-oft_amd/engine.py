@@ -302,9 +302,28 @@ class FullLinear:
 ACT_ID = {"gelu": ops.ACT_GELU, "gelu_tanh": ops.ACT_GELU_TANH}
 
 
+def lora_predicate(lora, has):
+    """`lora` True / False: every adapted Linear / none.  "auto": exactly the Linears whose adapter tensors are in the state dict -- a merged
+    checkpoint whose vision backbone still carries its adapters (the reference's FiLM evaluation path re-attaches LoRA to the towers only:
+    experiments/robot/openvla_utils.py:311-349) loads with adapters on the towers and none on the decoder."""
+    if lora == "auto":
+        if has is None:
+            raise ValueError('lora="auto" needs the state dict\'s `has`')
+
+        def pred(names):
+            flags = [has(n + ".lora_A.weight") for n in names]
+            if any(flags) != all(flags):
+                raise ValueError(f"LoRA adapters present for only some of the fused linears {names}")
+            return flags[0]
+
+        return pred
+    return lambda names: bool(lora)
+
+
 class VitTower:
-    def __init__(self, store, prefix: str, vc: VitConfig, get, cfg: VLAConfig, lora: bool, film: bool = False):
+    def __init__(self, store, prefix: str, vc: VitConfig, get, cfg: VLAConfig, lora, film: bool = False):
         self.vc, self.prefix = vc, prefix
+        lora = lora if callable(lora) else lora_predicate(lora, None)
         w = get(prefix + "patch_embed.proj.weight").reshape(vc.dim, -1)                 # [dim, 3*p*p]
         self.patch_w = torch.zeros((vc.dim, vc.patch_k), dtype=BF16, device=w.device)
         self.patch_w[:, : w.shape[1]] = w
@@ -321,8 +340,8 @@ class VitTower:
         s = cfg.lora_scale
 
         def L(name, groups=1):
-            A = get(name + ".lora_A.weight") if lora else None
-            Bm = get(name + ".lora_B.weight") if lora else None
+            A = get(name + ".lora_A.weight") if lora([name]) else None
+            Bm = get(name + ".lora_B.weight") if lora([name]) else None
             return LoraLinear(store, name, get(name + ".weight"), get(name + ".bias"), A, Bm, groups, s)
 
         # only blocks 0 .. depth-2 are ever used: the forward returns the output of block depth-2
@@ -344,6 +363,27 @@ class VitTower:
             yield from (b["qkv"], b["proj"], b["fc1"], b["fc2"])
             if b["film"] is not None:
                 yield from b["film"]
+
+    def export_frozen(self) -> Dict[str, torch.Tensor]:
+        """The tower's frozen tensors under their checkpoint names (views, no copies): what `vision_backbone--{step}_checkpoint.pt` carries
+        beside the adapters and the FiLM Linears (finetune.py:640-655 saves the whole wrapped backbone)."""
+        vc, p = self.vc, self.prefix
+        out = {p + "patch_embed.proj.weight": self.patch_w[:, : 3 * vc.patch * vc.patch].reshape(vc.dim, 3, vc.patch, vc.patch),
+               p + "patch_embed.proj.bias": self.patch_b, p + "pos_embed": self.pos.reshape(1, vc.n_patches, vc.dim)}
+        if self.prefix_tokens is not None:
+            out[p + "cls_token"] = self.prefix_tokens[:1].reshape(1, 1, vc.dim)
+            if vc.n_prefix > 1:
+                out[p + "reg_token"] = self.prefix_tokens[1:].reshape(1, vc.n_prefix - 1, vc.dim)
+        for i, b in enumerate(self.blocks):
+            q = f"{p}blocks.{i}."
+            out.update({q + "norm1.weight": b["ln1_w"], q + "norm1.bias": b["ln1_b"], q + "norm2.weight": b["ln2_w"], q + "norm2.bias": b["ln2_b"]})
+            for nm, key in (("attn.qkv", "qkv"), ("attn.proj", "proj"), ("mlp.fc1", "fc1"), ("mlp.fc2", "fc2")):
+                if getattr(b[key], "merged", False):
+                    raise RuntimeError("the adapters were merged into the base weights: there is no training-time backbone state to export")
+                out[q + nm + ".weight"], out[q + nm + ".bias"] = b[key].W, b[key].bias
+            if b["ls1"] is not None:
+                out[q + "ls1.scale_factor"], out[q + "ls2.scale_factor"] = b["ls1"], b["ls2"]
+        return out
 
     def fwd(self, pixels, c0: int, n_img: int, train: bool, film_avg=None):
         """pixels bf16 [B, 6*n_img, H, W]; image i uses channels [c0 + 6 i, +3).  All images go through the tower as one
@@ -428,8 +468,9 @@ class VitTower:
 # Llama decoder stack (transformers LlamaModel; reference call site modeling_prismatic.py:632-643)
 # ======================================================================================================================
 class LlamaStack:
-    def __init__(self, store, cfg: VLAConfig, get, lora: bool):
+    def __init__(self, store, cfg: VLAConfig, get, lora):
         self.cfg = cfg
+        lora = lora if callable(lora) else lora_predicate(lora, None)
         D, F, s = cfg.llm_dim, cfg.llm_ff, cfg.lora_scale
         self.layers = []
         for i in range(cfg.llm_layers):
@@ -437,8 +478,9 @@ class LlamaStack:
 
             def fused(names, sub):
                 W = torch.cat([get(p + sub + n + ".weight") for n in names], 0)
-                A = torch.cat([get(p + sub + n + ".lora_A.weight") for n in names], 0) if lora else None
-                Bm = torch.cat([get(p + sub + n + ".lora_B.weight") for n in names], 0) if lora else None
+                on = lora([p + sub + n for n in names])
+                A = torch.cat([get(p + sub + n + ".lora_A.weight") for n in names], 0) if on else None
+                Bm = torch.cat([get(p + sub + n + ".lora_B.weight") for n in names], 0) if on else None
                 return LoraLinear(store, p + sub + "+".join(names), W, None, A, Bm, len(names), s, ref_names=[p + sub + n for n in names])
 
             self.layers.append(dict(
@@ -690,6 +732,7 @@ class VLAEngine:
             raise ValueError(head)
         ops.check_device(device.index or 0)
         self.cfg, self.device, self.lora = cfg, device, lora
+        lora = lora_predicate(lora, has)
         st = self.store = ParamStore(device)
         # registration order = forward order (the store reverses it into backward order)
         self.use_film = use_film
@@ -698,8 +741,8 @@ class VLAEngine:
         s = cfg.lora_scale
 
         def L(name):
-            return LoraLinear(st, name, get(name + ".weight"), get(name + ".bias"), get(name + ".lora_A.weight") if lora else None,
-                              get(name + ".lora_B.weight") if lora else None, 1, s)
+            return LoraLinear(st, name, get(name + ".weight"), get(name + ".bias"), get(name + ".lora_A.weight") if lora([name]) else None,
+                              get(name + ".lora_B.weight") if lora([name]) else None, 1, s)
 
         self.proj = [L("projector.fc1"), L("projector.fc2"), L("projector.fc3")]
         self.embed = get("language_model.model.embed_tokens.weight")
@@ -790,6 +833,17 @@ class VLAEngine:
             if m is not None:
                 for lin in m.linears():
                     lin.refresh_derived()
+
+    def vision_backbone_state_dict(self) -> Dict[str, torch.Tensor]:
+        """State dict of the (FiLM-wrapped, LoRA-adapted) vision backbone in the reference's key layout (weights.vision_backbone_keys_to_reference):
+        frozen tower tensors + the towers' adapters + the FiLM scale / shift Linears -- the content of `vision_backbone--{step}_checkpoint.pt`
+        (vla-scripts/finetune.py:640-655), which `get_vla(cfg)` with `cfg.use_film` loads back (experiments/robot/openvla_utils.py:311-349).
+        The discarded last block of each tower is not held by this engine and is absent."""
+        from .weights import vision_backbone_keys_to_reference
+
+        sd = {**self.dino.export_frozen(), **self.siglip.export_frozen()}
+        sd.update({k: v for k, v in self.export_trainable("data").items() if k.startswith("vision_backbone.")})
+        return vision_backbone_keys_to_reference(sd)
 
     def export_trainable(self, kind: str = "data") -> Dict[str, torch.Tensor]:
         """Every trainable tensor (or its fp32 gradient) keyed by the reference's parameter names: LoRA adapters as

@@ -73,13 +73,32 @@ def get_vla(cfg: Any, model_config: VLAConfig = OPENVLA_7B) -> OpenVLAForActionP
         sd.update(_load_tensors(shard))
     if not sd:
         raise ValueError(f"no *.safetensors shards in {ckpt}")
-    vla = OpenVLAForActionPrediction(model_config, sd, device=DEVICE)
+    use_film = bool(getattr(cfg, "use_film", False))
+    if use_film:
+        sd.update(_film_vision_backbone(cfg, model_config))
+    vla = OpenVLAForActionPrediction(model_config, sd, device=DEVICE, use_film=use_film)
     vla.vision_backbone.set_num_images_in_input(cfg.num_images_in_input)
     stats = ckpt / "dataset_statistics.json"
     if stats.is_file():                                                     # openvla_utils.py:352-377
         vla.norm_stats = json.loads(stats.read_text())
     vla.eval()
     return vla
+
+
+def _film_vision_backbone(cfg: Any, model_config: VLAConfig) -> Dict[str, torch.Tensor]:
+    """openvla_utils.py:311-349 (`_apply_film_to_vla`): the FiLM evaluation path re-attaches LoRA (r = 32, alpha = 16) to the model, wraps the
+    vision backbone with FiLM and loads `vision_backbone--{step}_checkpoint.pt` -- the WHOLE wrapped backbone as training saved it
+    (finetune.py:640-655): the towers' base weights, their adapters and the scale / shift Linears.  Those tensors replace the checkpoint
+    shards' vision backbone (whose adapters, in a merged checkpoint, are already folded in), exactly as `load_state_dict` does there; the
+    decoder and projector keep the shards' weights.  Returns the tensors under the engine's names."""
+    from ...weights import vision_backbone_keys_from_reference
+
+    if (model_config.lora_rank, model_config.lora_alpha) != (32, 16):
+        raise ValueError("the FiLM evaluation path re-creates the adapters with r=32, lora_alpha=16 (openvla_utils.py:325-332)")
+    part = vision_backbone_keys_from_reference(load_component_state_dict(find_checkpoint_file(cfg.pretrained_checkpoint, "vision_backbone")))
+    if not any(".scale.weight" in k for k in part):
+        raise ValueError("the vision_backbone checkpoint holds no FiLM scale / shift tensors")
+    return part
 
 
 def get_proprio_projector(cfg: Any, llm_dim: int, proprio_dim: int) -> ProprioProjector:

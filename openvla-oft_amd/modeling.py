@@ -367,8 +367,8 @@ class OpenVLAForActionPrediction(_StoreModule):
         self.cfg = cfg
         self.device = _device(device)
         get, has = make_getter(state_dict, self.device)
-        if lora is None:
-            lora = any(k.endswith(".lora_A.weight") for k in state_dict)
+        if lora is None:   # per Linear: a merged checkpoint may still carry the towers' adapters (the reference's FiLM evaluation path)
+            lora = "auto" if any(k.endswith(".lora_A.weight") for k in state_dict) else False
         if use_film is None:
             use_film = any(".scale.weight" in k for k in state_dict)
         self.engine = VLAEngine(cfg, get, self.device, lora=lora, use_proprio=False, head="none", has=has, use_film=use_film)

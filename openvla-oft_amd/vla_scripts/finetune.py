@@ -29,7 +29,7 @@ from ..dp import GradReducer
 from ..engine import VLAEngine
 from ..prismatic.training.train_utils import get_current_action_mask, get_next_actions_mask
 from ..prismatic.vla import constants as C
-from ..weights import load_lora_adapter, make_getter, random_state_dict, save_lora_adapter
+from ..weights import load_lora_adapter, make_getter, random_state_dict, save_lora_adapter, vision_backbone_keys_from_reference
 
 
 @dataclass
@@ -205,9 +205,15 @@ def save_training_checkpoint(run_dir: Path, log_step: int, engine: VLAEngine, da
         exp = {k: v.detach().to("cpu") for k, v in engine.export_trainable("data").items()}
         save_lora_adapter(ckpt / "lora_adapter", exp, r=engine.cfg.lora_rank, lora_alpha=engine.cfg.lora_alpha)   # peft on-disk format
         for comp, prefix in _COMPONENT_PREFIXES.items():
+            if comp == "vision_backbone":
+                continue
             sd = {k[len(prefix):]: v.contiguous() for k, v in exp.items() if k.startswith(prefix) and ".lora_" not in k}
             if sd:
                 torch.save(sd, ckpt / f"{comp}--{suffix}.pt")
+        if engine.use_film:
+            # finetune.py:640-655: the whole FiLM-wrapped backbone (frozen towers + their adapters + scale / shift), in the reference's key layout,
+            # so that get_vla(cfg.use_film) -- here or in the reference -- finds what _apply_film_to_vla loads (openvla_utils.py:311-349)
+            torch.save({k: v.detach().to("cpu").contiguous() for k, v in engine.vision_backbone_state_dict().items()}, ckpt / f"vision_backbone--{suffix}.pt")
         if save_optimizer:
             from safetensors.torch import save_file
 
@@ -231,7 +237,11 @@ def load_training_checkpoint(ckpt: Path, log_step: Optional[int], engine: VLAEng
         f = ckpt / f"{comp}--{suffix}.pt"
         if f.is_file():
             part = remove_ddp_in_checkpoint(torch.load(str(f), weights_only=True, map_location="cpu"))
-            sd.update({prefix + k: v for k, v in part.items()})
+            if comp == "vision_backbone":    # reference key layout (or the FiLM-only files of earlier rounds); only the trainable tensors are taken
+                part = vision_backbone_keys_from_reference(part)
+                sd.update({k: v for k, v in part.items() if ".lora_" in k or ".scale." in k or ".shift." in k})
+            else:
+                sd.update({prefix + k: v for k, v in part.items()})
     missing = engine.load_trainable(sd, strict=False)
     opt = ckpt / f"optimizer_state--{suffix}.safetensors"
     loaded_opt = False

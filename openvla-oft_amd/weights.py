@@ -158,3 +158,46 @@ def load_lora_adapter(adapter_dir) -> tuple[Dict[str, torch.Tensor], dict]:
         k = k.replace(".lora_A.default.", ".lora_A.").replace(".lora_B.default.", ".lora_B.")
         out[k] = v
     return out, cfg
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# `vision_backbone--{step}_checkpoint.pt`: the FiLM-wrapped backbone's state dict as the reference writes and reads it
+# ----------------------------------------------------------------------------------------------------------------------
+def vision_backbone_keys_to_reference(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Engine / HF-checkpoint names (`vision_backbone.featurizer.blocks.3.attn.qkv.weight`, `.lora_A.weight`, `blocks.3.scale.weight`) ->
+    the key layout of `FiLMedPrismaticVisionBackbone.state_dict()` after peft's `get_peft_model`, which is what
+    vla-scripts/finetune.py:640-655 saves and experiments/robot/openvla_utils.py:340-342 loads: the wrapper holds the backbone as
+    `.vision_backbone` (film_vit_wrapper.py:192), every block sits under `.block` of its FiLM wrapper (:49-54) with `scale` / `shift` beside it,
+    and peft renames an adapted Linear's tensors to `base_layer.{weight,bias}` / `lora_{A,B}.default.weight`."""
+    out = {}
+    for k, v in sd.items():
+        if not k.startswith("vision_backbone."):
+            continue
+        parts = k.split(".")
+        if "blocks" in parts:
+            i = parts.index("blocks")
+            if parts[i + 2] not in ("scale", "shift"):
+                parts.insert(i + 2, "block")
+        k2 = ".".join(parts)
+        if ".lora_A.weight" in k2 or ".lora_B.weight" in k2:
+            k2 = k2.replace(".lora_A.weight", ".lora_A.default.weight").replace(".lora_B.weight", ".lora_B.default.weight")
+        elif any(k2.endswith(f".{lin}.{t}") for lin in ("qkv", "proj", "fc1", "fc2") for t in ("weight", "bias")) and ".patch_embed." not in k2:
+            stem, t = k2.rsplit(".", 1)
+            if stem + ".lora_A.default.weight" in out or (k.rsplit(".", 1)[0] + ".lora_A.weight") in sd:
+                k2 = f"{stem}.base_layer.{t}"
+        out[k2] = v
+    return out
+
+
+def vision_backbone_keys_from_reference(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Inverse of `vision_backbone_keys_to_reference`, tolerant of DDP's `module.` prefix (finetune.py:134-156) and of files that hold the FiLM
+    tensors only (what this repo wrote before round 3: `featurizer.blocks.3.scale.weight`)."""
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("module."):
+            k = k[len("module."):]
+        if not k.startswith("vision_backbone."):
+            k = "vision_backbone." + k
+        k = k.replace(".block.", ".").replace(".base_layer.", ".").replace(".lora_A.default.", ".lora_A.").replace(".lora_B.default.", ".lora_B.")
+        out[k] = v
+    return out

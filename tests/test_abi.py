@@ -81,3 +81,34 @@ def test_integration_md_struct_matches_header():
     hdr = [(n, t.__name__) for n, t in lib_mod.STRUCTS["ovla_gemm_args"]._fields_]
     assert [n for n, _ in doc_fields] == [n for n, _ in hdr]
     assert all(kinds[d] == h or (d == "c_int64" and h in ("c_long", "c_longlong")) for (_, d), (_, h) in zip(doc_fields, hdr))
+
+
+def test_shipped_code_object_has_no_packed_fp32(libmod, tmp_path):
+    """The product library must be free of the compiler's packed-FP32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 /
+    v_pk_mov_b32): a gfx950 hazard drops a term of such an accumulate when another stream's waves share the SIMD (DESIGN.md "Run-to-run
+    determinism", profiles/r02_norm_bwd_probe.md).  csrc/build.sh switches the target feature off for EVERY .hip file it compiles; this test
+    disassembles every gfx950 code object inside the built .so so that a new source file, a changed flag or another build mode cannot lose
+    the protection silently."""
+    import re
+    import shutil
+
+    objdump = Path("/opt/rocm/lib/llvm/bin/llvm-objdump")
+    if not objdump.exists():
+        pytest.skip("llvm-objdump not in this image")
+    so = tmp_path / "libovla_hip.so"
+    shutil.copy(libmod.LIB_PATH, so)
+    subprocess.run([str(objdump), "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)   # extracts the bundles next to `so`
+    objs = sorted(tmp_path.glob("libovla_hip.so.*gfx950*"))
+    n_src = len(list((ROOT / "openvla-oft_amd" / "csrc").glob("*.hip")))
+    assert 1 <= len(objs) <= n_src, f"{len(objs)} gfx950 code objects for {n_src} .hip sources"
+    bad, n_mfma = [], 0
+    pat = re.compile(r"\bv_pk_(add_f32|mul_f32|fma_f32|mov_b32)\b")
+    for o in objs:
+        text = subprocess.run([str(objdump), "-d", str(o)], check=True, capture_output=True, text=True).stdout
+        n_mfma += text.count("v_mfma_")
+        bad += [f"{o.name}: {ln.strip()}" for ln in text.splitlines() if pat.search(ln)][:5]
+    assert n_mfma > 500, "the disassembly must be the real kernels (MFMA instructions present)"
+    assert not bad, "packed-FP32 instructions in the shipped code object:\n" + "\n".join(bad)
+    # and build.sh compiles every .hip file of the directory with the flag
+    sh = (ROOT / "openvla-oft_amd" / "csrc" / "build.sh").read_text()
+    assert 'SRCS="$(ls *.hip' in sh and 'NOPK="$SRCS"' in sh

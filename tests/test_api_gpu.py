@@ -271,3 +271,68 @@ def test_deploy_server_act_endpoint(world):
         assert client.post("/act", json={"instruction": "no images"}).json() == "error"
     finally:
         world["vla"].enable_graph_replay(False)
+
+
+def test_film_train_to_eval_handoff_through_get_vla(world, tmp_path, dev):
+    """configs[4]'s train -> eval hand-off at the glue level (experiments/robot/openvla_utils.py:295-299, 311-349; finetune.py:640-655): two
+    FiLM + LoRA optimisation steps -> `save_training_checkpoint` (writes `vision_backbone--2_checkpoint.pt` = the whole FiLM-wrapped backbone in
+    the reference's key layout) -> merge script (merged shards next to the adapter) -> `get_vla(cfg)` with `cfg.use_film` (reads that file
+    through `find_checkpoint_file`, `module.` prefix tolerated) + `get_action_head` / `get_proprio_projector` -> `get_vla_action(use_film=True)`.
+    The effective evaluation model is the one the reference assembles: decoder + projector adapters MERGED, towers base + adapters UNMERGED + FiLM;
+    the in-memory training engine brought to the same state reproduces its actions BIT FOR BIT."""
+    from safetensors.torch import save_file
+
+    engine_mod, weights_mod, ft, utils, merge_mod = (load("openvla-oft_amd." + m) for m in (
+        "engine", "weights", "vla_scripts.finetune", "experiments.robot.openvla_utils", "vla_scripts.merge_lora_weights_and_save"))
+    ocfg, cfg = world["ocfg"], world["cfg"]
+    sd = {k: v.to(BF) for k, v in vo.random_state_dict(ocfg, seed=4, film=True).items()}
+    get, has = weights_mod.make_getter(sd, dev)
+    eng = engine_mod.VLAEngine(cfg, get, dev, lora=True, use_proprio=True, head="l1", use_film=True, has=has)
+    for i in range(2):
+        b = world["synth"].make_batch(2, seed=300 + i, prompt_lens=[9, 8], image_size=56)
+        eng.zero_grad(); eng.train_step_fwd_bwd(b); eng.adamw_step(2e-3); eng.refresh_derived()
+    ck = ft.save_training_checkpoint(tmp_path / "run", 2, eng, world["stats"], rank=0)
+    vb = torch.load(ck / "vision_backbone--2_checkpoint.pt", weights_only=True)
+    assert "vision_backbone.featurizer.blocks.0.block.attn.qkv.base_layer.weight" in vb and "vision_backbone.featurizer.blocks.0.scale.weight" in vb
+    assert "vision_backbone.fused_featurizer.blocks.1.block.mlp.fc1.lora_A.default.weight" in vb and vb["vision_backbone.featurizer.blocks.0.scale.weight"].dtype == torch.float32
+    torch.save({"module." + k: v for k, v in vb.items()}, ck / "vision_backbone--2_checkpoint.pt")        # as the reference's DDP wrapper saves it
+    base_dir = tmp_path / "base"; base_dir.mkdir()
+    base = {k: v.contiguous() for k, v in sd.items() if k.startswith(("vision_backbone.", "projector.", "language_model.")) and ".lora_" not in k
+            and ".scale." not in k and ".shift." not in k}
+    save_file(base, str(base_dir / "model.safetensors"))
+    merge_mod.main(merge_mod.ConvertConfig(base_checkpoint=base_dir, lora_finetuned_checkpoint_dir=ck), model_config=cfg, device=dev)
+    rcfg = types.SimpleNamespace(pretrained_checkpoint=str(ck), use_film=True, use_l1_regression=True, use_diffusion=False, num_images_in_input=2,
+                                 use_proprio=True, center_crop=True, unnorm_key="libero_spatial_no_noops", num_open_loop_steps=8,
+                                 load_in_8bit=False, load_in_4bit=False)
+    vla = utils.get_vla(rcfg, model_config=cfg)
+    assert vla.engine.use_film and vla.norm_stats == world["stats"]
+    assert all(l.has_lora for l in vla.engine.dino.linears() if hasattr(l, "has_lora")) and not any(l.has_lora for l in vla.engine.llm.linears())
+    head, pp = utils.get_action_head(rcfg, vla.llm_dim), utils.get_proprio_projector(rcfg, vla.llm_dim, 8)
+
+    class P56(utils.PrismaticProcessor):       # the tiny test towers take 56 x 56 inputs
+        def __call__(self, text, image):
+            out = super().__call__(text, image)
+            out["pixel_values"] = out["pixel_values"][:, :, ::4, ::4].contiguous()
+            return out
+
+    rng = np.random.default_rng(3)
+    obs = {"full_image": rng.integers(0, 256, (224, 224, 3), dtype=np.uint8), "wrist_image": rng.integers(0, 256, (224, 224, 3), dtype=np.uint8),
+           "state": rng.uniform(-1, 1, 8)}
+    tok = lambda text: [1] + [3 + (ord(c) % 200) for c in text][:20]  # noqa: E731
+    seen = {}
+    orig = vla.predict_action
+    vla.predict_action = lambda **kw: (seen.update(kw), orig(**kw))[1]
+    acts = utils.get_vla_action(rcfg, vla, P56(tok), obs, "pick up the bowl", action_head=head, proprio_projector=pp, use_film=True)
+    with pytest.raises(ValueError):
+        utils.get_vla_action(rcfg, vla, P56(tok), dict(obs, state=rng.uniform(-1, 1, 8)), "pick up the bowl", action_head=head, proprio_projector=pp, use_film=False)
+    # the training engine in the evaluation state the reference assembles: decoder + projector merged, towers as trained
+    for lin in list(eng.llm.linears()) + list(eng.proj):
+        lin.merge()
+    ids = torch.cat([seen["input_ids"], torch.tensor([[29871]])], 1) if int(seen["input_ids"][0, -1]) != 29871 else seen["input_ids"]
+    ids = torch.cat([ids, torch.ones((1, 56), dtype=torch.int64), torch.tensor([[2]])], 1)
+    labels = torch.full_like(ids, -100); labels[:, -57:] = 31744; labels[:, -1] = 2
+    out = eng.forward(ids, torch.ones_like(ids, dtype=torch.bool), seen["pixel_values"], labels, proprio=torch.as_tensor(seen["proprio"], dtype=torch.float32),
+                      train=False, sel="actions")
+    pred = eng.head.fwd(eng.action_hidden(out)[0])[0].float().cpu().numpy().reshape(8, 7)
+    want = vla._unnormalize_actions(pred, "libero_spatial_no_noops")
+    assert np.array_equal(np.stack(acts), want), f"get_vla(use_film) actions differ from the in-memory model's by {np.abs(np.stack(acts) - want).max():.3e}"

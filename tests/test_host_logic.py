@@ -201,3 +201,62 @@ def test_deploy_wire_codec_roundtrip():
     assert double2 and np.array_equal(back2["full_image"], obs["full_image"])
     with pytest.raises(AssertionError, match="Only uses encoded payload"):
         d.decode_payload({"encoded": "{}", "x": 1})
+
+
+def test_vision_backbone_checkpoint_key_layout_roundtrip():
+    """`vision_backbone--{step}_checkpoint.pt` in the reference's layout (FiLMedPrismaticVisionBackbone over peft-wrapped towers:
+    finetune.py:640-655, film_vit_wrapper.py:49-54,192, peft's base_layer / lora_X.default naming) <-> the engine's names."""
+    w = importlib.import_module("openvla-oft_amd.weights")
+    eng = {f"vision_backbone.featurizer.blocks.3.attn.qkv.{t}": i for i, t in enumerate(("weight", "bias", "lora_A.weight", "lora_B.weight"))}
+    eng.update({"vision_backbone.featurizer.blocks.3.scale.weight": 5, "vision_backbone.featurizer.blocks.3.shift.bias": 6,
+                "vision_backbone.featurizer.blocks.3.norm1.weight": 7, "vision_backbone.featurizer.blocks.3.ls1.scale_factor": 8,
+                "vision_backbone.featurizer.patch_embed.proj.weight": 9, "vision_backbone.featurizer.pos_embed": 10,
+                "vision_backbone.fused_featurizer.blocks.0.mlp.fc1.weight": 11, "projector.fc1.weight": 12})
+    ref = w.vision_backbone_keys_to_reference(eng)
+    assert "projector.fc1.weight" not in ref
+    assert ref["vision_backbone.featurizer.blocks.3.block.attn.qkv.base_layer.weight"] == 0
+    assert ref["vision_backbone.featurizer.blocks.3.block.attn.qkv.lora_A.default.weight"] == 2
+    assert ref["vision_backbone.featurizer.blocks.3.scale.weight"] == 5 and ref["vision_backbone.featurizer.blocks.3.block.ls1.scale_factor"] == 8
+    assert ref["vision_backbone.featurizer.patch_embed.proj.weight"] == 9
+    assert ref["vision_backbone.fused_featurizer.blocks.0.block.mlp.fc1.weight"] == 11, "a Linear without adapters keeps its plain name"
+    back = w.vision_backbone_keys_from_reference({"module." + k: v for k, v in ref.items()})
+    assert back == {k: v for k, v in eng.items() if k.startswith("vision_backbone.")}
+    assert w.vision_backbone_keys_from_reference({"featurizer.blocks.3.scale.weight": 1}) == {"vision_backbone.featurizer.blocks.3.scale.weight": 1}
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did(monkeypatch):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: the process starts N children through torch.distributed.run on 127.0.0.1 BEFORE any
+    torch.cuda call and returns their status; under a launcher (WORLD_SIZE set) it does not."""
+    import subprocess
+    import sys
+
+    bench = importlib.import_module("bench")
+    calls = []
+
+    def fake_run(cmd, env=None, **kw):
+        calls.append((cmd, env))
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+
+    def no_cuda(*a, **k):
+        raise AssertionError("the launcher parent must not touch the GPU")
+
+    import torch
+
+    monkeypatch.setattr(torch.cuda, "set_device", no_cuda)
+    monkeypatch.setattr(torch.cuda, "is_available", no_cuda)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "WORLD_SIZE" not in env
+    # a mismatch under a launcher is an error message, not a silent single-rank run
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=2" in str(e.value.code) and len(calls) == 1

@@ -321,3 +321,180 @@ def test_g15_tower_wiring_matches_transformers(tag, vc):
     assert got.shape == want.shape
     err = (got - want).abs().max().item()
     assert err < 5e-5, err
+
+
+# ======================================================================================================================
+# G16-G19: vectors produced by the reference's OWN modeling_prismatic.py / film_vit_wrapper.py (tests/golden/make_golden_ref_model.py)
+# ======================================================================================================================
+def _ref_sd(g, diffusion=False):
+    """The fixtures carry the seed of the oracle's `random_state_dict` their weights came from, and a checksum of the tensors."""
+    sd = vo.random_state_dict(vo.tiny_config(), seed=int(g["sd_seed"]), lora=False, film=True, diffusion=diffusion)
+    chk = sum(float(v.double().abs().sum()) for v in sd.values())
+    assert np.isclose(chk, float(g["sd_diffusion_checksum" if diffusion else "sd_checksum"]), rtol=1e-12), "seeded weights drifted from the fixture's"
+    return sd
+
+
+def test_g16_projector_forward_and_gradients_match_reference():
+    """modeling_prismatic.py:231-262 (fused-backbone branch) executed by the reference itself."""
+    g = load("g16_ref_projector.npz")
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in g.items() if k.startswith("projector.")}
+    o = vo.Oracle(vo.tiny_config(), sd)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = o.projector(x)
+    assert np.allclose(y.detach().numpy(), g["y"], atol=2e-6, rtol=1e-5)
+    y.backward(torch.from_numpy(g["dy"]))
+    assert np.allclose(x.grad.numpy(), g["dx"], atol=2e-6, rtol=1e-4)
+    for k, v in sd.items():
+        assert np.allclose(v.grad.numpy(), g["grad." + k[len("projector."):]], atol=1e-5, rtol=1e-4), k
+
+
+def test_g17_multimodal_helpers_match_reference():
+    """modeling_prismatic.py:395-496 (masks, embedding replacement, multimodal concat of embeddings / mask / labels, proprio token),
+    :734-770 (placeholder ids / labels of predict_action), :772-791 (un-normalisation, both normalisation types)."""
+    g = load("g17_ref_multimodal_helpers.npz")
+    labels, amask = torch.from_numpy(g["labels"]), torch.from_numpy(g["attention_mask"])
+    m = vo.all_actions_mask(labels, 7)
+    assert np.array_equal(m.numpy(), g["all_actions_mask"]) and (m.sum(1) == 56).all()
+    emb, patches, feats = (torch.from_numpy(g[k]) for k in ("emb", "patches", "noisy_features"))
+    # the oracle's in-line restatement of _replace_input_embeddings / the zeroing branch (Oracle.multimodal_hidden)
+    rep = emb.clone()
+    for b in range(emb.shape[0]):
+        rep[b, m[b]] = feats[b]
+    assert np.array_equal(rep.numpy(), g["replaced"])
+    mm = torch.cat([emb[:, :1], patches, emb[:, 1:]], dim=1)
+    ones = torch.ones(patches.shape[:2], dtype=torch.bool)
+    assert np.array_equal(mm.numpy(), g["mm_emb"])
+    assert np.array_equal(torch.cat([amask[:, :1], ones, amask[:, 1:]], dim=1).numpy(), g["mm_mask"])
+    mm_labels = torch.cat([labels[:, :1], torch.full(patches.shape[:2], -100, dtype=labels.dtype), labels[:, 1:]], dim=1)
+    assert np.array_equal(mm_labels.numpy(), g["mm_labels"])
+    o = vo.Oracle(vo.tiny_config(), {k[3:].replace("fc", "p.fc"): torch.from_numpy(v) for k, v in g.items() if k.startswith("pp.")})
+    pf = o.mlp_projector(torch.from_numpy(g["proprio"]), "p.")
+    assert np.allclose(torch.cat((patches, pf[:, None, :]), dim=1).numpy(), g["with_proprio"], atol=2e-6)
+    # predict_action's input preparation: the oracle builds ids / mask / labels the same way (Oracle.predict_action)
+    pid = torch.from_numpy(g["prompt_ids"])
+    ids = torch.cat([pid, torch.ones((1, 56), dtype=pid.dtype), torch.full((1, 1), vo.STOP_INDEX, dtype=pid.dtype)], dim=-1)
+    lab = torch.full_like(ids, vo.IGNORE_INDEX)
+    lab[:, pid.shape[-1]:] = vo.ACTION_TOKEN_BEGIN_IDX + 1
+    lab[:, -1] = vo.STOP_INDEX
+    assert np.array_equal(ids.numpy(), g["prepared_ids"]) and np.array_equal(lab.numpy(), g["prepared_labels"])
+    assert g["prepared_mask"].all() and g["prepared_mask"].shape == ids.shape
+    stats = {k[len("stats."):]: v for k, v in g.items() if k.startswith("stats.")}
+    assert np.allclose(vo.unnormalize_actions(g["normalized"], stats, "bounds_q99"), g["unnorm_q99"], rtol=0, atol=0)
+    assert np.allclose(vo.unnormalize_actions(g["normalized"], stats, "bounds"), g["unnorm_bounds"], rtol=0, atol=0)
+    assert np.allclose(vo.unnormalize_actions(g["normalized"], {k: v for k, v in stats.items() if k != "mask"}, "bounds"), g["unnorm_bounds_nomask"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("tower", ["dino", "siglip"])
+def test_g18_film_block_forward_and_gradients_match_reference(tower):
+    """film_vit_wrapper.py:56-77 executed by the reference around a duck-typed block (LayerScale / none)."""
+    g = load("g18_ref_film_backbone.npz")
+    cfg = vo.tiny_config()
+    prefix, vc = (("vision_backbone.featurizer.", cfg.dino) if tower == "dino" else ("vision_backbone.fused_featurizer.", cfg.siglip))
+    sd = _ref_sd(g)
+    p = prefix + "blocks.1."
+    for nm in ("scale.weight", "scale.bias", "shift.weight", "shift.bias"):
+        sd[p + nm] = sd[p + nm].clone().requires_grad_(True)
+    o = vo.Oracle(cfg, sd)
+    x, avg = torch.from_numpy(g[tower + ".x"]).requires_grad_(True), torch.from_numpy(g[tower + ".avg"]).requires_grad_(True)
+    y = o.vit_block(x, p, vc, avg)
+    assert np.allclose(y.detach().numpy(), g[tower + ".y"], atol=3e-5, rtol=1e-5)
+    y.backward(torch.from_numpy(g[tower + ".dy"]))
+    assert np.allclose(x.grad.numpy(), g[tower + ".dx"], atol=3e-5, rtol=1e-4)
+    assert np.allclose(avg.grad.numpy(), g[tower + ".davg"], atol=2e-4, rtol=1e-4)
+    for nm in ("scale.weight", "scale.bias", "shift.weight", "shift.bias"):
+        assert np.allclose(sd[p + nm].grad.numpy(), g[f"{tower}.grad.{nm}"], atol=2e-4, rtol=1e-4), nm
+
+
+@pytest.mark.parametrize("n_img", [1, 2, 3])
+def test_g18_vision_backbones_match_reference(n_img):
+    """PrismaticVisionBackbone.forward (modeling_prismatic.py:186-227) and FiLMedPrismaticVisionBackbone.forward (film_vit_wrapper.py:231-276, with
+    the reference's own get_intermediate_layers :114-168): block index depth-2, prefix tokens dropped, no final norm, feature / image concat order,
+    the language average."""
+    g = load("g18_ref_film_backbone.npz")
+    cfg = vo.tiny_config(num_images=n_img)
+    o = vo.Oracle(cfg, _ref_sd(g))
+    pv, lang = torch.from_numpy(g[f"backbone.i{n_img}.pixel_values"]), torch.from_numpy(g[f"backbone.i{n_img}.language"])
+    with torch.no_grad():
+        assert np.allclose(o.vision_backbone(pv).numpy(), g[f"backbone.i{n_img}.plain"], atol=5e-5)
+        assert np.allclose(o.vision_backbone(pv, lang.mean(dim=1)).numpy(), g[f"backbone.i{n_img}.film"], atol=5e-5)
+
+
+def _g19_batch(g):
+    return {k: torch.from_numpy(g[k]) for k in ("input_ids", "attention_mask", "labels", "pixel_values", "proprio", "actions")}
+
+
+@pytest.mark.parametrize("film", [False, True])
+@pytest.mark.parametrize("mode", ["causal", "bidirectional"])
+def test_g19_forward_matches_reference(mode, film):
+    """PrismaticForConditionalGeneration.forward, multimodal branch (modeling_prismatic.py:571-643) executed by the reference with stock HF Llama
+    underneath: hidden_states[-1], logits (band + argmax + logsumexp), the shifted cross entropy, projector features; L1 (zeroed action
+    embeddings) and diffusion (noisy-action embeddings + timestep token) inputs; with and without FiLM."""
+    g = load("g19_ref_forward_predict.npz")
+    cfg = vo.tiny_config()
+    tag = f"{mode}.{'film' if film else 'plain'}"
+    valid = g["attention_mask"]
+    b = _g19_batch(g)
+    with torch.no_grad():
+        o = vo.Oracle(cfg, _ref_sd(g), mask_mode=mode)
+        hidden, P = o.multimodal_hidden(b["input_ids"], b["attention_mask"], b["pixel_values"], b["labels"], b["proprio"], use_film=film)
+        mm_valid = np.concatenate([valid[:, :1], np.ones((valid.shape[0], P), bool), valid[:, 1:]], axis=1)
+        assert np.abs(hidden.numpy() - g[tag + ".l1.hidden"])[mm_valid].max() < 1e-4
+        logits = o.lm_logits(hidden)
+        assert np.array_equal(logits.argmax(-1).numpy()[mm_valid], g[tag + ".l1.logits_argmax"][mm_valid])
+        assert np.abs(torch.logsumexp(logits, -1).numpy() - g[tag + ".l1.logits_lse"])[mm_valid].max() < 2e-4
+        if not film:
+            assert np.abs(logits[..., 31700:32064].numpy() - g[tag + ".l1.logits_band"])[mm_valid].max() < 2e-4
+        loss, _ = o.train_forward_discrete(b) if not film else (None, None)
+        if loss is not None:
+            assert abs(loss.item() - float(g[tag + ".l1.loss"])) < 1e-4
+        if mode == "causal":
+            feats = o.projector(o.vision_backbone(b["pixel_values"], None if not film else o.W("language_model.model.embed_tokens.weight")[b["input_ids"]][
+                ~vo.all_actions_mask(b["labels"], 7)].reshape(3, -1, cfg.llm_dim).mean(1)))
+            pf = o.mlp_projector(b["proprio"], "proprio_projector.")
+            assert np.allclose(torch.cat((feats, pf[:, None]), 1).numpy(), g[tag + ".l1.projector_features"], atol=1e-4)
+        # diffusion-style inputs
+        od = vo.Oracle(cfg, _ref_sd(g, diffusion=True), mask_mode=mode)
+        temb = vo.sinusoidal_encoding(torch.from_numpy(g["timesteps"]), cfg.llm_dim)[:, None, :]
+        hidden, P = od.multimodal_hidden(b["input_ids"], b["attention_mask"], b["pixel_values"], b["labels"], b["proprio"],
+                                         torch.from_numpy(g["noisy_actions"]), temb, use_film=film)
+        mm_valid = np.concatenate([valid[:, :1], np.ones((valid.shape[0], P), bool), valid[:, 1:]], axis=1)
+        assert np.abs(hidden.numpy() - g[tag + ".diffusion.hidden"])[mm_valid].max() < 1e-4
+
+
+@pytest.mark.parametrize("film", [False, True])
+@pytest.mark.parametrize("mode", ["causal", "bidirectional"])
+def test_g19_predict_action_matches_reference(mode, film):
+    """OpenVLAForActionPrediction.predict_action (modeling_prismatic.py:946-1060) executed by the reference: L1 head and discrete decode, a prompt
+    that ends with the empty token and one that does not, un-normalised with BOUNDS_Q99 statistics."""
+    g = load("g19_ref_forward_predict.npz")
+    cfg = vo.tiny_config()
+    tag = f"{mode}.{'film' if film else 'plain'}"
+    stats = {k[len("stats."):]: v for k, v in g.items() if k.startswith("stats.")}
+    o = vo.Oracle(cfg, _ref_sd(g), mask_mode=mode)
+    pv, prop = torch.from_numpy(g["pixel_values"][:1]), g["proprio"][0]
+    with torch.no_grad():
+        for ptag, key in (("p", "prompt_ids"), ("pno", "prompt_ids_no_empty")):
+            pid = torch.from_numpy(g[key])
+            am = torch.ones_like(pid, dtype=torch.bool)
+            act, ah = o.predict_action(pid, am, pv, proprio=prop, unnorm_stats=stats, use_film=film, head="l1")
+            assert np.abs(ah.numpy() - g[f"{tag}.predict.{ptag}.l1.hidden"]).max() < 1e-4
+            assert np.abs(act - g[f"{tag}.predict.{ptag}.l1.actions"]).max() < 1e-4
+            act, _ = o.predict_action(pid, am, pv, proprio=prop, unnorm_stats=stats, use_film=film, head="discrete")
+            assert np.array_equal(act, g[f"{tag}.predict.{ptag}.discrete.actions"]), "discrete decode: identical bin centres"
+
+
+@pytest.mark.parametrize("mode", ["causal", "bidirectional"])
+def test_g19_diffusion_predict_action_loop_matches_reference(mode):
+    """The reference's denoising loop (modeling_prismatic.py:793-877: timestep token appended to the patches, noisy-action embeddings scattered into the
+    action slots, slicing of the action rows, vision patches reused) around the oracle's own DDIM -- pins the wiring, not the scheduler."""
+    g = load("g19_ref_forward_predict.npz")
+    cfg = vo.tiny_config()
+    stats = {k[len("stats."):]: v for k, v in g.items() if k.startswith("stats.")}
+    o = vo.Oracle(cfg, _ref_sd(g, diffusion=True), mask_mode=mode)
+    pid = torch.from_numpy(g["prompt_ids"])
+    with torch.no_grad():
+        act, ah = o.predict_action(pid, torch.ones_like(pid, dtype=torch.bool), torch.from_numpy(g["pixel_values"][:1]), proprio=g["proprio"][0],
+                                   unnorm_stats=stats, use_film=True, head="diffusion", noise=torch.from_numpy(g["diffusion.start_noise"]),
+                                   num_diffusion_steps=int(g["diffusion.T"]))
+    assert np.abs(ah.numpy() - g[f"{mode}.film.predict.p.diffusion.hidden"]).max() < 2e-4
+    assert np.abs(act - g[f"{mode}.film.predict.p.diffusion.actions"]).max() < 2e-4
