@@ -248,3 +248,38 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ======================================================================================================================
+# a seeded state dict CONDITIONED LIKE A TRAINED MODEL (tests/test_fullsize_e2e_gpu.py: the absolute-tolerance tests)
+# ======================================================================================================================
+ACTION_ID0, N_ACTION_IDS = 31744, 256      # prismatic/vla/constants.py:12 (ACTION_TOKEN_BEGIN_IDX + 1) .. vocab 32000 (action_tokenizer.py:30-47)
+
+
+def conditioned_state_dict(cfg, dev, seed: int = 1, *, branch_gain: float = 0.25, head_gain: float = 0.25, lm_gain: float = 4.0):
+    """`weights.random_state_dict` re-conditioned so that absolute parity numbers mean something (no checkpoint exists offline):
+
+      * residual branches: every block's OUTPUT projection (decoder o_proj / down_proj, ViT attn.proj / mlp.fc2, their biases and adapter B
+        factors) is scaled by `branch_gain`, so a block adds a fraction of the stream's magnitude as trained transformers do -- with N(0, 0.02..0.03)
+        output projections every block rewrites the stream and a bf16 rounding of a branch is a rounding of the whole state;
+      * action head: `fc2` scaled by `head_gain` so the predicted actions live in [-1, 1] (the normalised action range, constants.py:26-52)
+        instead of +-4, where one output ulp is 4x coarser;
+      * lm_head: zero except the 256 action-token rows, which are `lm_gain` x an orthonormal block: the action logits are then 256 independent
+        projections of the hidden state with an O(lm_gain) spread, i.e. most rows have a real top-2 margin (a random N(0, 0.05) lm_head gives
+        every one of 32 064 ids a chance and no margin anywhere).
+    Returns the state dict (bf16, on `dev`)."""
+    load = importlib.import_module
+    weights_mod = load("openvla-oft_amd.weights")
+    sd = weights_mod.random_state_dict(cfg, dev, seed=seed, lm_head=True)
+    for k in list(sd):
+        out_proj = any(t in k for t in (".self_attn.o_proj.", ".mlp.down_proj.", ".attn.proj.", ".mlp.fc2."))
+        if out_proj and (k.endswith(".weight") or k.endswith(".bias")) and ".lora_A." not in k:
+            sd[k] = (sd[k].float() * branch_gain).to(BF)
+    for k in ("action_head.model.fc2.weight", "action_head.model.fc2.bias"):
+        sd[k] = (sd[k].float() * head_gain).to(BF)
+    g = torch.Generator(device=dev).manual_seed(seed + 77)
+    q, _ = torch.linalg.qr(torch.randn(cfg.llm_dim, N_ACTION_IDS, generator=g, device=dev, dtype=torch.float32))
+    lm = torch.zeros_like(sd["language_model.lm_head.weight"])
+    lm[ACTION_ID0: ACTION_ID0 + N_ACTION_IDS] = (lm_gain * q.T).to(BF)
+    sd["language_model.lm_head.weight"] = lm
+    return sd

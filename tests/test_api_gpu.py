@@ -319,10 +319,11 @@ def test_film_train_to_eval_handoff_through_get_vla(world, tmp_path, dev):
     obs = {"full_image": rng.integers(0, 256, (224, 224, 3), dtype=np.uint8), "wrist_image": rng.integers(0, 256, (224, 224, 3), dtype=np.uint8),
            "state": rng.uniform(-1, 1, 8)}
     tok = lambda text: [1] + [3 + (ord(c) % 200) for c in text][:20]  # noqa: E731
-    seen = {}
+    seen, rec = {}, {}
     orig = vla.predict_action
-    vla.predict_action = lambda **kw: (seen.update(kw), orig(**kw))[1]
+    vla.predict_action = lambda **kw: (rec.update(kw), orig(**kw))[1]
     acts = utils.get_vla_action(rcfg, vla, P56(tok), obs, "pick up the bowl", action_head=head, proprio_projector=pp, use_film=True)
+    seen = dict(rec)                           # (the spy also records the refused call below)
     with pytest.raises(ValueError):
         utils.get_vla_action(rcfg, vla, P56(tok), dict(obs, state=rng.uniform(-1, 1, 8)), "pick up the bowl", action_head=head, proprio_projector=pp, use_film=False)
     # the training engine in the evaluation state the reference assembles: decoder + projector merged, towers as trained
