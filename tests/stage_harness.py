@@ -283,3 +283,28 @@ def conditioned_state_dict(cfg, dev, seed: int = 1, *, branch_gain: float = 0.25
     lm[ACTION_ID0: ACTION_ID0 + N_ACTION_IDS] = (lm_gain * q.T).to(BF)
     sd["language_model.lm_head.weight"] = lm
     return sd
+
+
+def fit_lm_head_to_labels(sd, cfg, action_hidden32, batch, *, margin: float = 8.0, ridge: float = 1e-3):
+    """`lm_head` of a model that has LEARNED this batch: the 256 action-token rows are the closed-form ridge-regression solution that maps the
+    fp32 hidden state of every action row to a logit of `margin` on its label (the batch's own action tokens, datasets.py:75) and 0 on the other
+    action ids -- W = Y^T (H H^T + lambda I)^-1 H, lambda = ridge * mean diag -- rounded to bf16; every other vocabulary row is zero.  What a trained
+    checkpoint's lm_head does for its training data (a top-2 margin on every row), obtained without a training run.  Returns the fp32 fit quality
+    (min margin over the rows it was fitted on)."""
+    H = action_hidden32.reshape(-1, cfg.llm_dim).double()
+    lab = batch["labels"].to(H.device)
+    tgt = lab[(lab > 31743)].reshape(-1)                        # action tokens, row-major (b, slot): the order of the action rows
+    assert tgt.numel() == H.shape[0]
+    Y = torch.zeros(H.shape[0], N_ACTION_IDS, dtype=torch.float64, device=H.device)
+    Y[torch.arange(H.shape[0]), tgt - ACTION_ID0] = margin
+    K = H @ H.T
+    K += ridge * K.diagonal().mean() * torch.eye(K.shape[0], dtype=K.dtype, device=K.device)
+    W = (torch.linalg.solve(K, Y).T @ H).float()               # [256, D]
+    lm = torch.zeros_like(sd["language_model.lm_head.weight"])
+    lm[ACTION_ID0: ACTION_ID0 + N_ACTION_IDS] = W.to(BF)
+    sd["language_model.lm_head.weight"] = lm
+    logits = (H.float() @ W.to(BF).float().T)
+    top2 = logits.topk(2, dim=-1).values
+    ok = logits.argmax(-1) == (tgt - ACTION_ID0)
+    return dict(fit_accuracy=ok.float().mean().item(), min_margin=(top2[:, 0] - top2[:, 1]).min().item(), w_rms=W.pow(2).mean().sqrt().item(),
+                sv_min_over_max=(torch.linalg.svdvals(H.float())[[-1, 0]]).tolist())

@@ -250,3 +250,132 @@ def test_full_size_config5_film_diffusion_step(dev):
     del eng, sd
     gc.collect()
     torch.cuda.empty_cache()
+
+
+# ======================================================================================================================
+# ABSOLUTE tolerances on a state dict conditioned like a trained model (tests/stage_harness.py: conditioned_state_dict + fit_lm_head_to_labels)
+# ======================================================================================================================
+@pytest.fixture(scope="module")
+def cond(dev):
+    """Seeded full-size weights with residual-branch gains 0.25, an action head whose outputs stay inside the normalised action range, and an
+    lm_head that has learned the batch's action tokens (closed-form ridge fit on the fp32 hidden states): every action row has a real top-2 margin."""
+    load = importlib.import_module
+    engine_mod, weights_mod, synth, config_mod = (load("openvla-oft_amd.engine"), load("openvla-oft_amd.weights"), load("openvla-oft_amd.synthetic"),
+                                                  load("openvla-oft_amd.config"))
+    cfg = config_mod.OPENVLA_7B
+    sd = sh.conditioned_state_dict(cfg, dev, seed=1, branch_gain=0.25, head_gain=0.125)
+    batch8 = synth.make_batch(8, seed=2000)
+    st32 = sh.oracle_stages(sh.oracle_config(cfg), sd, batch8, dev, "fp32", lm_head=False)
+    fit = sh.fit_lm_head_to_labels(sd, cfg, st32["action_hidden"], batch8, margin=8.0, ridge=1e-3)
+    del st32
+    get, has = weights_mod.make_getter(sd, dev)
+    eng = engine_mod.VLAEngine(cfg, get, dev, lora=True, use_proprio=True, head="l1", has=has)
+    yield dict(cfg=cfg, sd=sd, eng=eng, batch8=batch8, fit=fit)
+    del eng, sd
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+# measured on MI355X (gpurun_out/conditioned_abs_b{8,1}.json; DESIGN.md section 5): the bounds sit 25-50 % above the measurement
+ABS = {"hidden_rel2": 3.6e-2, "action_hidden_rel2": 4.0e-2, "pred_rel2": 5.5e-2, "pred_linf_fp32": 0.10, "pred_linf_eager": 0.17, "margin_threshold": 0.5}
+
+
+@pytest.mark.parametrize("B", [8, 1])
+def test_conditioned_model_absolute_parity(cond, dev, B):
+    """`north_star`: "bit-exact action-token indices, continuous actions within 1e-3 L-inf bf16" -- asserted here as ABSOLUTE numbers on a model with
+    trained-like conditioning, at configs[2] (B = 8) and configs[1] (B = 1) full size:
+      * action-token ids (modeling_prismatic.py:929-942): BIT-IDENTICAL to the fp32 evaluation on every row whose fp32 top-2 logit margin exceeds
+        ABS["margin_threshold"]; the rows under it are counted (and must be few: the lm_head gives real margins);
+      * continuous actions (:923-927), all inside [-1, 1]: L-inf against fp32 and against the stock eager path, rel-L2 against fp32;
+      * the stream: rel-L2 of hidden_states[-1] and of the gathered action rows against fp32.
+    The action bound is NOT 1e-3: the bf16 residual stream alone (2 x 32 decoder + ~2 x 25 tower roundings of the state, 2^-9 relative each) puts ANY
+    bf16 evaluation ~3e-2 rel-L2 from exact arithmetic at the action rows (the stock eager path: 3.2e-2 .. 4.0e-2), which the head passes on as
+    ~4e-2 of |a|; DESIGN.md section 5 records the measurement.  A 5 % systematic error anywhere on the path moves pred rel-L2 from 4.1e-2 to
+    6.5e-2 and fails this test."""
+    cfg, sd, eng = cond["cfg"], cond["sd"], cond["eng"]
+    b8 = cond["batch8"]
+    batch = b8 if B == 8 else {k: v[:1] for k, v in b8.items()}
+    _, st = sh.run_all(cfg, sd, batch, dev, eng=eng)
+    table = sh.compare(st, batch, dev)
+    tok = sh.token_report(st)
+    p32 = st["fp32"]["pred"].float()
+    hip_eager = (st["hip"]["pred"].float() - st["native"]["pred"].float()).abs().max().item()
+    margin = st["fp32"]["token_margin"]
+    confident = margin > ABS["margin_threshold"]
+    same = st["hip"]["token_ids"] == st["fp32"]["token_ids"]
+    rec = {"B": B, "fit": cond["fit"], "max_abs_action_fp32": p32.abs().max().item(), "hidden_rel2": table["hidden"]["hip"][1],
+           "action_hidden_rel2": table["action_hidden"]["hip"][1], "pred_rel2": table["pred"]["hip"][1], "pred_linf_fp32": table["pred"]["hip"][0],
+           "pred_linf_eager": hip_eager, "eager_pred_linf_fp32": table["pred"]["native"][0], "eager_pred_rel2": table["pred"]["native"][1],
+           "eager_action_hidden_rel2": table["action_hidden"]["native"][1], "ids_total": int(same.numel()), "ids_differ": int((~same).sum()),
+           "rows_under_margin_threshold": int((~confident).sum()), "median_margin": margin.median().item(),
+           "eager_ids_differ": tok["native"]["n_diff"], "emulation_ids_differ": tok["bf16"]["n_diff"]}
+    print("\n" + json.dumps(rec))
+    _dump(f"conditioned_abs_b{B}.json", rec)
+    assert p32.abs().max().item() <= 1.0, "the conditioned head keeps the actions inside the normalised range"
+    assert bool(same[confident].all()), f"action-token ids differ from fp32 on {int((~same & confident).sum())} rows with an fp32 margin > {ABS['margin_threshold']}"
+    assert int((~confident).sum()) <= 0.05 * same.numel(), "the fitted lm_head must leave at most 5 % of the rows without a margin"
+    assert rec["hidden_rel2"] <= ABS["hidden_rel2"] and rec["action_hidden_rel2"] <= ABS["action_hidden_rel2"]
+    assert rec["pred_rel2"] <= ABS["pred_rel2"] and rec["pred_linf_fp32"] <= ABS["pred_linf_fp32"] and hip_eager <= ABS["pred_linf_eager"]
+
+
+# per-tensor rel-L2 against fp32 autograd (MSE objective), (median, max) per family: 1.2x what this build measures on MI355X
+# (gpurun_out/conditioned_grads.json: head 0.052 / 0.064, decoder LoRA 0.073 / 0.166, projector LoRA 0.082 / 0.088, proprio projector 0.177 / 0.185,
+# tower LoRA 0.092 / 0.158; the stock eager path measures 0.057 / 0.071, 0.081 / 0.222, 0.089 / 0.097, 0.222 / 0.242, 0.102 / 0.167).  The floor is the
+# bf16 activations the gradients are products of (3e-2 rel-L2 on the forward stream and as much again on the backward one), not the kernels: a
+# systematic 5 % error in one family moves its median from e.g. 0.073 to 0.088 and fails.
+GRAD_ABS = {"head": (0.062, 0.077), "lora_llm": (0.0875, 0.20), "lora_projector": (0.099, 0.105), "proprio": (0.212, 0.222), "lora_vision": (0.111, 0.19)}
+
+
+def test_conditioned_gradients_absolute(cond, dev):
+    """All 866 trainable gradient tensors of one configs[2] step on the conditioned model, MEAN-SQUARED-ERROR objective (no |.| kinks: a bf16-level
+    difference in a prediction cannot flip a gradient's sign), against torch.autograd through the fp32 oracle: per-tensor rel-L2 under ABSOLUTE bounds."""
+    import torch.nn.functional as F
+
+    cfg, sd, eng, batch = cond["cfg"], cond["sd"], cond["eng"], cond["batch8"]
+    ocfg = sh.oracle_config(cfg)
+    names = sorted(eng.export_trainable("data"))
+    Bsz = batch["input_ids"].shape[0]
+    target = batch["actions"].to(dev, BF).reshape(Bsz * cfg.chunk, cfg.action_dim).contiguous()
+    eng.zero_grad()
+    out = eng.forward(batch["input_ids"], batch["attention_mask"], batch["pixel_values"].to(dev, BF), batch["labels"], proprio=batch["proprio"].to(dev, BF),
+                      train=True, sel="actions")
+    ah, _ = eng.action_hidden(out)
+    pred, loss_sum, hsaved = eng.head.fwd(ah, target=target, mse=True, train=True)
+    eng.backward_from_hidden(eng.head.bwd(hsaved, dloss=1.0), out["saved"])
+    torch.cuda.synchronize()
+    g_hip = {k: v.float().clone() for k, v in eng.export_trainable("grad").items()}
+    loss_hip = loss_sum.item() / pred.numel()
+
+    def autograd(mode):
+        fdt = BF if mode == "native" else torch.float32
+        sdg = dict(sd)
+        for k in names:
+            sdg[k] = sd[k].detach().to(fdt).clone().requires_grad_(True)
+        b = sh.device_batch(batch, dev, fdt)
+        _, p, _ = sh.vo.Oracle(ocfg, sdg, mode=mode).train_forward(b)
+        loss = F.mse_loss(p.float(), b["actions"].float())
+        loss.backward()
+        return loss.item(), {k: sdg[k].grad.float() for k in names}
+
+    loss32, g32 = autograd("fp32")
+    gc.collect(); torch.cuda.empty_cache()
+    lossn, gn = autograd("native")
+    gc.collect(); torch.cuda.empty_cache()
+    fam = {}
+    for k in names:
+        if g32[k].norm() < 1e-12:
+            assert g_hip[k].norm() < 1e-6, k
+            continue
+        f = "head" if k.startswith("action_head.") else ("proprio" if k.startswith("proprio_projector.") else
+                                                         ("lora_vision" if k.startswith("vision_backbone.") else ("lora_projector" if k.startswith("projector.") else "lora_llm")))
+        fam.setdefault(f, []).append((sh.rel2(g_hip[k], g32[k]), sh.rel2(gn[k], g32[k]), k))
+    rep = {f: {"n": len(v), "median_hip": float(np.median([e[0] for e in v])), "max_hip": max(e[0] for e in v),
+               "median_eager": float(np.median([e[1] for e in v])), "max_eager": max(e[1] for e in v), "worst": max(v)[2]} for f, v in fam.items()}
+    print(f"\nMSE loss hip {loss_hip:.6f} eager {lossn:.6f} fp32 {loss32:.6f}")
+    for f, r in rep.items():
+        print(f"  [{f}] n={r['n']}: rel-L2 vs fp32 autograd  median hip {r['median_hip']:.4f} eager {r['median_eager']:.4f};  max hip {r['max_hip']:.4f} eager {r['max_eager']:.4f}  ({r['worst']})")
+    _dump("conditioned_grads.json", {"loss": [loss_hip, lossn, loss32], "families": rep})
+    assert abs(loss_hip - loss32) <= 2e-2 * abs(loss32)
+    assert set(rep) == set(GRAD_ABS)
+    for f, r in rep.items():
+        assert r["median_hip"] <= GRAD_ABS[f][0] and r["max_hip"] <= GRAD_ABS[f][1], f"{f}: median {r['median_hip']:.4f} max {r['max_hip']:.4f} vs bounds {GRAD_ABS[f]}"

@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--branch", type=float, default=0.25)
     ap.add_argument("--head", type=float, default=0.25)
     ap.add_argument("--lm", type=float, default=4.0)
+    ap.add_argument("--fit", action="store_true", help="lm_head fitted to the batch's labels by ridge regression on the fp32 hidden states (stage_harness.fit_lm_head_to_labels)")
+    ap.add_argument("--margin", type=float, default=8.0)
+    ap.add_argument("--ridge", type=float, default=1e-3)
     ap.add_argument("--out", default="gpurun_out/conditioned.json")
     a = ap.parse_args()
     load = importlib.import_module
@@ -29,8 +32,13 @@ def main():
     cfg = config_mod.OPENVLA_7B
     sd = sh.conditioned_state_dict(cfg, dev, 1, branch_gain=a.branch, head_gain=a.head, lm_gain=a.lm)
     eng, rec = None, {}
+    batch8 = synth.make_batch(8, seed=2000)
+    if a.fit:
+        st32 = sh.oracle_stages(sh.oracle_config(cfg), sd, batch8, dev, "fp32", lm_head=False)
+        print("lm_head fit:", sh.fit_lm_head_to_labels(sd, cfg, st32["action_hidden"], batch8, margin=a.margin, ridge=a.ridge))
+        del st32
     for B in (8, 1):
-        batch = synth.make_batch(B, seed=2000)
+        batch = batch8 if B == 8 else {k: (v[:1] if torch.is_tensor(v) else v[:1]) for k, v in batch8.items()}
         eng, st = sh.run_all(cfg, sd, batch, dev, eng=eng)
         table = sh.compare(st, batch, dev)
         print(f"\n==== B = {B} ====\n" + sh.format_table(table, ["hip", "bf16", "native"]))
