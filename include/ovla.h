@@ -126,6 +126,26 @@ int ovla_gemm_tn_bf16(const ovla_gemm_tn_args* a, void* stream);
 #define OVLA_TN_MAX_GROUP 4
 int ovla_gemm_tn_grouped(const ovla_gemm_tn_args* problems, int32_t n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * LoRA backward, the two products that stream dy, in ONE pass over it (peft LoRA r = 32 on every nn.Linear, finetune.py:862-871; autograd's
+ * backward of `result + lora_B(lora_A(x)) * scaling`):
+ *     dt[:, g r : (g+1) r]  = bf16(scale * dy_g . B_g)        dy_g = dy[:, g gn : (g+1) gn], B_g [gn, r] given transposed (Bt rows g r ..)
+ *     dB[g gn : (g+1) gn]  += dy_g^T . t[:, g r : (g+1) r]    fp32, atomically accumulated (dB must hold the running sum)
+ * for the G fused groups of one adapted Linear (q|k|v: 3, gate|up: 2).  dt partial sums of the 256-column chunks go through the fp32
+ * workspace and are added in a fixed order: dt is bit-reproducible run to run.  r must be 32. */
+typedef struct {
+  const void* dy; int64_t ld_dy;   /* bf16 [M, G*gn] */
+  const void* Bt; int64_t ld_bt;   /* bf16 [G*r, gn]: B_g^T stacked */
+  const void* t;  int64_t ld_t;    /* bf16 [M, G*r]: the forward's saved  scale * x . A_g^T */
+  void* dt; int64_t ld_dt;         /* out bf16 [M, G*r] */
+  float* dB; int64_t ld_db;        /* in/out fp32 [G*gn, r] */
+  int32_t M, gn, G, r;
+  float scale;
+  void* workspace; int64_t workspace_bytes;   /* >= ovla_lora_bwd_workspace_bytes(M, gn, G), 16-byte aligned */
+} ovla_lora_bwd_args;
+int64_t ovla_lora_bwd_workspace_bytes(int32_t M, int32_t gn, int32_t G);
+int ovla_lora_bwd(const ovla_lora_bwd_args* a, void* stream);
+
 /* column sums  out[n] (+)= sum_m X[m,n]   (bias gradients).  out fp32, atomic accumulate. */
 typedef struct { const void* X; int64_t ldx; float* out; int32_t M, N; } ovla_colsum_args;
 int ovla_colsum_bf16(const ovla_colsum_args* a, void* stream);

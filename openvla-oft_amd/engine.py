@@ -48,6 +48,8 @@ _FUSE_ACT, _FUSE_SWIGLU = _FUSE in ("act", "all"), _FUSE in ("swiglu", "all")
 # more than the kernel boundaries they replace (a boundary is 1.5-1.9 us on this chip).  Default: fused for more than 16 rows, unfused below;
 # OVLA_FUSE_HEAD=0 / 1 forces one path everywhere.
 _FUSE_HEAD = {"0": False, "1": True}.get(os.environ.get("OVLA_FUSE_HEAD", "auto"), None)
+# OVLA_LORA_BWD=0: the LoRA backward as a skinny NT GEMM (dt) + TN GEMMs (dB, dA) instead of the one-pass kernel (A/B switch).
+_LORA_BWD_FUSED = os.environ.get("OVLA_LORA_BWD", "1") != "0"
 
 
 # ======================================================================================================================
@@ -227,11 +229,16 @@ class LoraLinear:
             raise RuntimeError(f"{self.name}: LoRA adapters were merged into the base weight; this engine is inference-only")
         if self.has_lora:
             r, G, gn = self.r, self.groups, self.group_n
-            # dt[:, g] = s * dy_g . B_g for every fused group in ONE block-diagonal skinny GEMM
-            dt = ops.gemm(dy, self.BT, alpha=self.scale, a_group_n=r if G > 1 else 0)
-            # dB_g += dy_g^T t_g ; dA += dt^T x : one grouped launch
-            probs = [(dy[:, g * gn:(g + 1) * gn], t_s[:, g * r:(g + 1) * r], self.B.grad[g * gn:(g + 1) * gn]) for g in range(G)]
-            probs.append((dt, x, self.A.grad))
+            if _LORA_BWD_FUSED and r == 32 and dy.shape[0] >= 512:
+                # ONE pass over dy: dt = s * dy_g . B_g and dB_g += dy_g^T t_g together (csrc/lora_bwd.hip); only dA += dt^T x is left to the TN GEMM
+                dt = ops.lora_bwd(dy, self.BT, t_s, self.B.grad, gn=gn, G=G, scale=self.scale)
+                probs = [(dt, x, self.A.grad)]
+            else:
+                # dt[:, g] = s * dy_g . B_g for every fused group in ONE block-diagonal skinny GEMM
+                dt = ops.gemm(dy, self.BT, alpha=self.scale, a_group_n=r if G > 1 else 0)
+                # dB_g += dy_g^T t_g ; dA += dt^T x : one grouped launch
+                probs = [(dy[:, g * gn:(g + 1) * gn], t_s[:, g * r:(g + 1) * r], self.B.grad[g * gn:(g + 1) * gn]) for g in range(G)]
+                probs.append((dt, x, self.A.grad))
             if tn_queue is not None:
                 tn_queue.extend(probs)
             else:

@@ -191,6 +191,29 @@ def gemm_tn_grouped(problems):
     _prof_end(e0, "gemm_tn", flops)
 
 
+def lora_bwd(dy, Bt, t, dB_grad, *, gn, G, scale, dt=None):
+    """One pass over dy for a LoRA linear's backward (ovla.h: ovla_lora_bwd): returns dt [M, G*r] bf16 = scale * dy_g . B_g per group and
+    accumulates dB_grad [G*gn, r] fp32 += dy_g^T . t_g.  Bt: [G*r, gn] (B_g^T stacked), t: [M, G*r] (the forward's saved scale * x . A^T)."""
+    _chk(dy, name="dy"); _chk(Bt, name="Bt"); _chk(t, name="t")
+    M = dy.shape[0]
+    r = Bt.shape[0] // G
+    assert dy.shape[1] == G * gn and Bt.shape == (G * r, gn) and t.shape == (M, G * r) and dB_grad.shape == (G * gn, r) and dB_grad.dtype == torch.float32
+    assert dy.stride(1) == 1 and Bt.stride(1) == 1 and t.stride(1) == 1 and dB_grad.stride(1) == 1
+    if dt is None:
+        dt = torch.empty((M, G * r), dtype=BF16, device=dy.device)
+    need = _lib.lib().ovla_lora_bwd_workspace_bytes(M, gn, G)
+    ws = _workspace(dy.device, need)
+    g = STRUCTS["ovla_lora_bwd_args"]()
+    g.dy, g.ld_dy, g.Bt, g.ld_bt, g.t, g.ld_t = dy.data_ptr(), dy.stride(0), Bt.data_ptr(), Bt.stride(0), t.data_ptr(), t.stride(0)
+    g.dt, g.ld_dt, g.dB, g.ld_db = dt.data_ptr(), dt.stride(0), dB_grad.data_ptr(), dB_grad.stride(0)
+    g.M, g.gn, g.G, g.r, g.scale = M, gn, G, r, scale
+    g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    e0 = _prof_begin()
+    _lib.call("ovla_lora_bwd", g, _stream())
+    _prof_end(e0, "lora_bwd", 4.0 * M * G * gn * r)
+    return dt
+
+
 def transpose_table(pairs, device):
     """Builds the device descriptor table for transpose_batched from [(src, dst)] (2-D bf16 tensors that never move)."""
     import ctypes

@@ -697,3 +697,29 @@ def test_fused_head_tail_is_bit_identical_to_the_unfused_sequence(dev, D, rows, 
     ref = F.linear(F.layer_norm(h, (D,), w("layer_norm2.weight"), w("layer_norm2.bias"), 1e-5), w("fc2.weight"), w("fc2.bias"))
     err = (pf.float().cpu() - ref).abs().max().item()
     assert err < 3e-2 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("M,gn,G", [(300, 264, 1), (1216, 512, 3), (4176, 1152, 1), (1000, 4304, 2)])
+def test_lora_bwd_one_pass(ops, dev, M, gn, G):
+    """ovla_lora_bwd: dt = bf16(s * dy_g . B_g) and dB_g += dy_g^T t_g from ONE staging of dy (peft LoRA backward, finetune.py:862-871), against
+    torch fp32 on the bf16-exact operands: ragged row counts, a column count that is no multiple of the 256-column chunk, fused groups, an
+    existing dB that is accumulated into; dt bit-identical between two runs (its chunk partials are added in a fixed order)."""
+    r, s = 32, 0.5
+    dy, t = rnd(M, G * gn, dev=dev), rnd(M, G * r, dev=dev)
+    Bt = rnd(G * r, gn, dev=dev, scale=0.3)
+    dB0 = torch.randn(G * gn, r, device=dev)
+    dB = dB0.clone()
+    dt = ops.lora_bwd(dy, Bt, t, dB, gn=gn, G=G, scale=s)
+    for g in range(G):
+        dyg, tg, Btg = dy[:, g * gn:(g + 1) * gn].float(), t[:, g * r:(g + 1) * r].float(), Bt[g * r:(g + 1) * r].float()
+        close(dt[:, g * r:(g + 1) * r], s * (dyg @ Btg.T), what=f"dt group {g}")
+        ref = dyg.T @ tg
+        err = ((dB[g * gn:(g + 1) * gn] - dB0[g * gn:(g + 1) * gn]) - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-5, f"dB group {g}: rel err {err:.3e} (fp32 accumulation of exact bf16 products)"
+    dB2 = dB0.clone()
+    dt2 = ops.lora_bwd(dy, Bt, t, dB2, gn=gn, G=G, scale=s)
+    assert torch.equal(dt, dt2), "dt must be bit-reproducible (it feeds the data-gradient chain)"
+    # and it equals what the two-kernel path computes, up to the bf16 rounding of differently ordered fp32 sums
+    dt_old = ops.gemm(dy, Bt, alpha=s, a_group_n=r if G > 1 else 0) if (G == 1 or gn % 128 == 0) else None
+    if dt_old is not None:
+        assert (dt.float() - dt_old.float()).abs().max().item() <= 2.0 ** -7 * dt_old.float().abs().max().item()
