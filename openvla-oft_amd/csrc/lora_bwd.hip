@@ -7,7 +7,7 @@
 // kernel the two were a block-diagonal skinny NT GEMM (+ its split-K reduce) and a TN GEMM, each streaming dy -- 40 .. 214 MB per Linear at
 // the fine-tune shapes -- from HBM / the Infinity Cache once: 0.83 GB per decoder layer for 0.1 % of its FLOPs.  Here a workgroup owns a
 // (row range, 256-column chunk) of dy_g and walks the rows in steps of 64; each step's [64 x 256] tile is staged once in LDS (row-major,
-// coalesced 16-byte loads, register-staged one step ahead) and feeds BOTH products:
+// coalesced 16-byte loads, register-staged two steps ahead) and feeds BOTH products:
 //   * dt: wave w takes rows 16 w .. 16 w + 15 of the step; mfma_f32_16x16x32_bf16 with the operands swapped (B_g^T fragment as A operand, the
 //     dy fragment -- a plain 16-byte LDS row read -- as B operand), so a lane owns 4 consecutive r-columns of one row; the 16 B_g^T fragments of
 //     the chunk are loop-invariant and live in registers.  The chunk's partial sums go to an fp32 slab [chunk][M][r] with plain 16-byte stores;
@@ -18,6 +18,7 @@
 //     128-byte row segments of dB: the shape float atomics run at full rate with, gemm_tn.hip).
 // HBM-bound: algorithmic bytes = M * G * gn * 2 (dy once) + the slab round trip (gn / 256 * M * r * 8).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -82,35 +83,38 @@ __global__ __launch_bounds__(256) void lora_bwd_kernel(const LoraBwdParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) accB[a][r] = 0.f;
 
-  // register staging: 8 chunks of the dy tile + 1 of the t tile per thread, one step ahead
-  bf16x8_bits rdy[8], rt;
-  auto load = [&](int m0) {
+  // register staging, TWO steps ahead (two register sets used alternately: the loads of step s + 2 are issued while step s computes, so a
+  // workgroup keeps two 36 KB tiles in flight and a CU's two resident workgroups four -- one tile ahead left the loop waiting ~1.5 us per
+  // step for its own loads: 2.3-2.6 TB/s)
+  bf16x8_bits rdy[2][8], rt[2];
+  auto load = [&](int m0, auto set_tag) {
+    constexpr int S = decltype(set_tag)::value;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int id = tid + 256 * i, rr = id >> 5, ch = id & 31;
       const int m = m0 + rr, c = c0 + ch * 8;
-      rdy[i] = (m < m_end && c < p.gn) ? *reinterpret_cast<const bf16x8_bits*>(dy + (int64_t)m * p.ld_dy + ch * 8) : zero8;
+      rdy[S][i] = (m < m_end && c < p.gn) ? *reinterpret_cast<const bf16x8_bits*>(dy + (int64_t)m * p.ld_dy + ch * 8) : zero8;
     }
     const int rr = tid >> 2, ch = tid & 3;
-    rt = (m0 + rr < m_end) ? *reinterpret_cast<const bf16x8_bits*>(tg + (int64_t)(m0 + rr) * p.ld_t + ch * 8) : zero8;
+    rt[S] = (m0 + rr < m_end) ? *reinterpret_cast<const bf16x8_bits*>(tg + (int64_t)(m0 + rr) * p.ld_t + ch * 8) : zero8;
   };
-  auto store = [&]() {
+  auto store = [&](auto set_tag) {
+    constexpr int S = decltype(set_tag)::value;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int id = tid + 256 * i;
-      *reinterpret_cast<bf16x8_bits*>(s_dy + (id >> 5) * LB_SD + (id & 31) * 8) = rdy[i];
+      *reinterpret_cast<bf16x8_bits*>(s_dy + (id >> 5) * LB_SD + (id & 31) * 8) = rdy[S][i];
     }
-    *reinterpret_cast<bf16x8_bits*>(s_t + (tid >> 2) * LB_ST + (tid & 3) * 8) = rt;
+    *reinterpret_cast<bf16x8_bits*>(s_t + (tid >> 2) * LB_ST + (tid & 3) * 8) = rt[S];
   };
 
   float* slab = p.slab + ((int64_t)(g * p.chunks + chunk) * p.M) * LB_R;
-  if (nsteps > 0) load(m_begin);
-  for (int st = 0; st < nsteps; ++st) {
+  auto step = [&](int st, auto set_tag) {
     const int m0 = m_begin + st * LB_ROWS;
     __syncthreads();            // the previous step's fragment reads are done
-    store();
+    store(set_tag);
     __syncthreads();
-    if (st + 1 < nsteps) load(m0 + LB_ROWS);
+    if (st + 2 < nsteps) load(m0 + 2 * LB_ROWS, set_tag);
     // ---- dt partial of rows m0 + 16 wave .. + 15 over this chunk's 256 columns ----
     f32x4 accT[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     const bf16_bits* arow = s_dy + (16 * wave + (lane & 15)) * LB_SD + 8 * (lane >> 4);
@@ -138,6 +142,12 @@ __global__ __launch_bounds__(256) void lora_bwd_kernel(const LoraBwdParams p) {
         accB[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yf, accB[a], 0, 0, 0);
       }
     }
+  };
+  if (nsteps > 0) load(m_begin, std::integral_constant<int, 0>{});
+  if (nsteps > 1) load(m_begin + LB_ROWS, std::integral_constant<int, 1>{});
+  for (int st = 0; st < nsteps; st += 2) {
+    step(st, std::integral_constant<int, 0>{});
+    if (st + 1 < nsteps) step(st + 1, std::integral_constant<int, 1>{});
   }
   // D[n][j]: col j = lane & 31, row n = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll

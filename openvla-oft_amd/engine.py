@@ -48,8 +48,11 @@ _FUSE_ACT, _FUSE_SWIGLU = _FUSE in ("act", "all"), _FUSE in ("swiglu", "all")
 # more than the kernel boundaries they replace (a boundary is 1.5-1.9 us on this chip).  Default: fused for more than 16 rows, unfused below;
 # OVLA_FUSE_HEAD=0 / 1 forces one path everywhere.
 _FUSE_HEAD = {"0": False, "1": True}.get(os.environ.get("OVLA_FUSE_HEAD", "auto"), None)
-# OVLA_LORA_BWD=0: the LoRA backward as a skinny NT GEMM (dt) + TN GEMMs (dB, dA) instead of the one-pass kernel (A/B switch).
-_LORA_BWD_FUSED = os.environ.get("OVLA_LORA_BWD", "1") != "0"
+# OVLA_LORA_BWD=1: the LoRA backward's dt and dB from ONE pass over dy (csrc/lora_bwd.hip) instead of a skinny NT GEMM (dt) + TN GEMMs (dB, dA).
+# Built, parity-tested and measured in round 3 (tools/lora_bwd_bench.py, cold operands, M = 4864): 293.6 vs 272.4 us per decoder layer for the
+# three-kernel path -- reading dy once saves 0.4 GB per layer, but a 2-D (rows x 256-column) decomposition pays it back as fp32 partial-dt slabs
+# (+25 % of dy's bytes, written and read) and dB atomics (+21 %, at a quarter of the streaming rate); left OFF.
+_LORA_BWD_FUSED = os.environ.get("OVLA_LORA_BWD", "0") == "1"
 
 
 # ======================================================================================================================
