@@ -400,6 +400,7 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * args.batch * args.steps / elapsed
     final_loss = loss_sum.item() / (args.batch * cfg.chunk * cfg.action_dim)
+    eng.head.check_fused_tail()
 
     roofline = cpu = None
     # dominant kernel (gemm_nt) timed launch by launch with HIP events on the launch stream over one more step.  EVERY rank

@@ -407,8 +407,10 @@ int ovla_head_out_bwd(const ovla_head_out_bwd_args* a, void* stream);
  * epilogue | LayerNorm 2 + fc2 + loss.  LayerNorm stages deal ROWS over the workgroups and write the normalised rows (hb: the Linear's saved
  * input); GEMM stages deal 16-column strips: a workgroup streams ITS 16 weight rows from HBM once (each 33.5 MB matrix crosses HBM once,
  * spread over the chip) and reads the R x dim normalised rows from L2, one wave per 16-row MFMA tile.  The stages are separated by four
- * grid-wide barriers: agent-scope release / arrival counter / bounded spin / agent-scope acquire (the counter in `sync` is zeroed by a memset
- * node ahead of the launch; a spin that runs out sets sync[1] and poisons pred and loss_sum with NaN instead of hanging).
+ * grid-wide barriers: agent-scope release / arrival counter / bounded spin / agent-scope acquire (the arrival counter sync[0] is zeroed by a memset
+ * node ahead of the launch; a spin that runs out fills pred, loss_sum and every saved buffer with NaN and sets sync[1], which NO launch clears:
+ * the host reads it where it already synchronises).  The launch is refused unless the whole grid can be co-resident
+ * (ovla_head_tail_resident_blocks() = occupancy x compute units >= dim / 16 workgroups).
  * Arithmetic, rounding points AND summation orders are those of the unfused sequence (ovla_norm_fwd, ovla_gemm_bf16 with split_k = 2 and
  * its reduce epilogue, ovla_head_out_fwd): results are bit-identical to it (tests/test_kernels_gpu.py).
  * Everything the backward needs is written out when the pointers are given (training): per block the LayerNorm output hb (the Linear's
@@ -421,10 +423,11 @@ typedef struct {
   float* mean[2]; float* rstd[2];                   /* optional, [R] */
   const void* ln2_w; const void* ln2_b; void* h2; float* mean2; float* rstd2;   /* h2 required ([R, dim]); stats optional */
   const void* W2; const void* b2; void* pred; const void* target; float* loss_sum;   /* W2 [adim, dim]; target / loss_sum optional */
-  uint32_t* sync;                                   /* device, >= 2 words: arrival counter, timeout flag */
+  uint32_t* sync;                                   /* device, >= 2 words: arrival counter (reset per launch), STICKY timeout flag */
   int32_t rows, rows_real, dim, adim, mse, ksplit;  /* ksplit 1 | 2: accumulate K in that many halves, summed in order (= split_k of the unfused GEMM) */
   float eps;
 } ovla_head_tail_args;
+int ovla_head_tail_resident_blocks(void);          /* workgroups of the fused tail that fit on the current device at once (0: unknown / no device) */
 int ovla_head_tail_fwd(const ovla_head_tail_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -197,9 +197,20 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailParams p) 
   unsigned epoch = 0;
   auto barrier = [&]() -> bool {
     if (head_grid_barrier(p.sync, G * (++epoch), &bar_ok)) return true;
-    if (blockIdx.x == 0 && tid == 0) {   // poison the results: a timed-out barrier must not look like a success
-      if (p.loss_sum) *p.loss_sum = __builtin_nanf("");
-      p.pred[0] = 0x7fc0;
+    // A timed-out barrier (the grid was not co-resident) must not look like a success, here or in the backward that reads the saved tensors:
+    // every output and every saved buffer is filled with NaN (each workgroup its 16-column strips, workgroup 0 the small ones), and sync[1]
+    // -- which no launch ever clears -- stays set until the host reads it (ActionHead.check_fused_tail, called where the step already syncs).
+    const bf16_bits qnan = 0x7fc0;
+    for (int b = 0; b < 2; ++b) {
+      bf16_bits* bufs[3] = {p.hb[b], p.zb[b], p.xo[b]};
+      for (int q = 0; q < 3; ++q)
+        if (bufs[q])
+          for (int i = tid; i < R * 16 * strips; i += 256) bufs[q][(int64_t)(i / (16 * strips)) * D + blockIdx.x * 16 * strips + i % (16 * strips)] = qnan;
+    }
+    for (int i = tid; i < R * 16 * strips; i += 256) p.h2[(int64_t)(i / (16 * strips)) * D + blockIdx.x * 16 * strips + i % (16 * strips)] = qnan;
+    if (blockIdx.x == 0) {
+      for (int i = tid; i < p.rows_real * p.adim; i += 256) p.pred[i] = qnan;
+      if (tid == 0 && p.loss_sum) *p.loss_sum = __builtin_nanf("");
     }
     return false;
   };
@@ -217,17 +228,34 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailParams p) 
       // the two halves are independent accumulation chains: they run interleaved (twice the loads in flight, the matrix pipe never waits
       // on one chain), each in its own k order, so the sums are those of the two split-K workgroups of the unfused GEMM
       const int n_hi = ksteps - half;              // k-steps of the second half (0 when ksplit == 1; <= half)
-#pragma unroll 4
-      for (int ks = 0; ks < half && ks < ksteps; ++ks) {
+      // Weight rows and normalised rows stream straight into MFMA fragments (no LDS: every byte is used once per wave).  A register ring
+      // keeps PD k-steps of both chains in flight per wave -- 4 x PD 16-byte loads: round 2's loop had 4-8 and sat at 0.07 of the HBM
+      // roofline, one memory round trip per 4 KB.  The MFMA order of each chain is unchanged (k ascending), so the sums are bit-identical.
+      constexpr int PD = 8;
+      bf16x8_bits ra0[PD], rw0[PD], ra1[PD], rw1[PD];
+      const int lim = half < ksteps ? half : ksteps;
+      auto fetch = [&](int ks, int slot) {
         const int k = ks * 32 + kq;
-        const bf16x8_bits a0 = *reinterpret_cast<const bf16x8_bits*>(hr + k);
-        const bf16x8_bits w0 = *reinterpret_cast<const bf16x8_bits*>(wr + k);
+        ra0[slot] = *reinterpret_cast<const bf16x8_bits*>(hr + k);
+        rw0[slot] = *reinterpret_cast<const bf16x8_bits*>(wr + k);
         if (ks < n_hi) {
-          const bf16x8_bits a1 = *reinterpret_cast<const bf16x8_bits*>(hr + k + half * 32);
-          const bf16x8_bits w1 = *reinterpret_cast<const bf16x8_bits*>(wr + k + half * 32);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, a1, acc[1], 0, 0, 0);
+          ra1[slot] = *reinterpret_cast<const bf16x8_bits*>(hr + k + half * 32);
+          rw1[slot] = *reinterpret_cast<const bf16x8_bits*>(wr + k + half * 32);
         }
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, a0, acc[0], 0, 0, 0);
+      };
+#pragma unroll
+      for (int i = 0; i < PD; ++i)
+        if (i < lim) fetch(i, i);
+      for (int ks0 = 0; ks0 < lim; ks0 += PD) {
+#pragma unroll
+        for (int sl = 0; sl < PD; ++sl) {
+          const int ks = ks0 + sl;
+          if (ks < lim) {
+            if (ks < n_hi) acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rw1[sl], ra1[sl], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rw0[sl], ra0[sl], acc[0], 0, 0, 0);
+            if (ks + PD < lim) fetch(ks + PD, sl);
+          }
+        }
       }
       // epilogue = epilogue_store of gemm_nt.hip after its split-K reduce: (0 + p0) + p1, + bias, round, save z, ReLU, round, + residual, round
       const int n = n0 + 4 * (lane >> 4);
@@ -466,6 +494,18 @@ extern "C" int ovla_head_out_fwd(const ovla_head_out_fwd_args* a, void* stream_)
   return OVLA_OK;
 }
 
+extern "C" int ovla_head_tail_resident_blocks(void) {
+  static int cached = -1;
+  if (cached < 0) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, head_tail_kernel, 256, 0) != hipSuccess)
+      return 0;   // no device / query failed: nothing is known to be resident (not cached: a later call may succeed)
+    cached = cus * per_cu;
+  }
+  return cached;
+}
+
 extern "C" int ovla_head_tail_fwd(const ovla_head_tail_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   OVLA_REQUIRE(a && a->x0 && a->xo[0] && a->xo[1] && a->hb[0] && a->hb[1] && a->h2 && a->W2 && a->pred && a->sync && a->ln2_w && a->ln2_b, "ovla_head_tail_fwd: null pointer");
@@ -488,9 +528,14 @@ extern "C" int ovla_head_tail_fwd(const ovla_head_tail_args* a, void* stream_) {
   p.ln2_w = (const bf16_bits*)a->ln2_w; p.ln2_b = (const bf16_bits*)a->ln2_b; p.h2 = (bf16_bits*)a->h2; p.mean2 = a->mean2; p.rstd2 = a->rstd2;
   p.W2 = (const bf16_bits*)a->W2; p.b2 = (const bf16_bits*)a->b2; p.pred = (bf16_bits*)a->pred; p.target = (const bf16_bits*)a->target; p.loss_sum = a->loss_sum;
   p.sync = a->sync; p.R = a->rows; p.rows_real = a->rows_real; p.D = a->dim; p.adim = a->adim; p.mse = a->mse; p.ksplit = a->ksplit; p.eps = a->eps;
-  if (hipMemsetAsync(a->sync, 0, 2 * sizeof(uint32_t), stream) != hipSuccess) { ovla_set_error("ovla_head_tail_fwd: hipMemsetAsync failed"); return OVLA_ELAUNCH; }
   const int tiles_m = a->rows / 16, strips = tiles_m == 1 ? 4 : (tiles_m == 2 ? 2 : 1);
-  hipLaunchKernelGGL(head_tail_kernel, dim3(a->dim / 16 / strips), dim3(256), 0, stream, p);
+  const int grid = a->dim / 16 / strips;
+  // the kernel spins on software grid barriers: refuse the launch unless the whole grid can be resident at once on this device
+  OVLA_REQUIRE(ovla_head_tail_resident_blocks() >= grid, "ovla_head_tail_fwd: %d workgroups cannot be co-resident (%d fit): use the unfused sequence", grid,
+               ovla_head_tail_resident_blocks());
+  // sync[0] = arrival counter of THIS launch; sync[1] = sticky timeout flag: never cleared here, the host reads (and clears) it
+  if (hipMemsetAsync(a->sync, 0, sizeof(uint32_t), stream) != hipSuccess) { ovla_set_error("ovla_head_tail_fwd: hipMemsetAsync failed"); return OVLA_ELAUNCH; }
+  hipLaunchKernelGGL(head_tail_kernel, dim3(grid), dim3(256), 0, stream, p);
   OVLA_CHECK_LAUNCH("ovla_head_tail_fwd");
   return OVLA_OK;
 }

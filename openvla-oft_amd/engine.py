@@ -22,7 +22,7 @@ import os
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from .config import VLAConfig, VitConfig
 
 BF16 = torch.bfloat16
@@ -629,7 +629,8 @@ class ActionHead:
         split = 8 if rows <= 256 else 1      # small-M weight stream: split K over the chip
         x, s1 = self.fc1.fwd(h0, act=ops.ACT_RELU, c_pre=z1, split_k=split)
         D = cfg.llm_dim
-        if (rows > 16 if _FUSE_HEAD is None else _FUSE_HEAD) and rows <= 64 and D % 64 == 0 and D // 16 <= 256 and (D // 16) % 4 == 0:
+        if (rows > 16 if _FUSE_HEAD is None else _FUSE_HEAD) and rows <= 64 and D % 64 == 0 and D // 16 <= 256 and (D // 16) % 4 == 0 and \
+                _lib.lib().ovla_head_tail_resident_blocks() >= D // 16:      # software grid barriers: only when the whole grid is co-resident
             # everything after fc1 -- both MLPResNet blocks, LayerNorm 2, fc2 and the loss -- is ONE launch (ovla_head_tail_fwd), bit-identical
             # to the unfused sequence below; its backward is the unfused one, fed from the tensors the kernel saves
             R = (rows + 15) // 16 * 16
@@ -663,6 +664,16 @@ class ActionHead:
         pred = ops.head_out_fwd(h2[:rows_real], self.out_w.data, self.out_b.data, target, loss_sum, mse=mse)
         saved = (x0, m0, r0, z1, s1, blocks_saved, x, m2, r2, h2, pred, target, mse, rows_real) if train else None
         return pred, loss_sum, saved
+
+    def check_fused_tail(self):
+        """Host-side check of the fused tail's sticky timeout word (ovla_head_tail_args.sync[1]): call where the step already synchronises
+        (loss.item()).  A timed-out grid barrier has already turned the loss, the predictions and every saved buffer into NaN; this turns it
+        into an exception and clears the word."""
+        sync = getattr(self, "_sync", None)
+        if sync is not None and int(sync[1].item()) != 0:
+            sync[1] = 0
+            raise RuntimeError("ovla_head_tail_fwd: a grid barrier timed out (the workgroups were not co-resident); the step's head outputs are NaN. "
+                               "Set OVLA_FUSE_HEAD=0 to use the unfused sequence.")
 
     def bwd(self, saved, dloss: float = 1.0, dpred=None):
         """Returns d(actions_hidden) [B*A_tokens, D]; accumulates the head's gradients.  With `dpred` (bf16

@@ -180,6 +180,8 @@ def run_forward_pass(vla, action_head, noisy_action_projector, proprio_projector
                 pred = run_diffusion_sampling(vla, action_head, noisy_action_projector, proprio_projector, batch, B, num_patches, gt.shape, device_id,
                                               cur, nxt, use_proprio, use_film)
     metrics["loss_value"] = loss.item()
+    if action_head is not None and hasattr(action_head.module, "comp"):
+        action_head.module.comp.check_fused_tail()
     if pred is not None:                                                                # :437-448 (should_log_l1_loss)
         metrics["curr_action_l1_loss"] = torch.nn.L1Loss()(gt[:, 0], pred[:, 0]).item()
         metrics["next_actions_l1_loss"] = torch.nn.L1Loss()(gt[:, 1:], pred[:, 1:]).item()
@@ -402,6 +404,8 @@ def finetune(cfg: FinetuneConfig, *, model_config: VLAConfig = OPENVLA_7B, state
             engine.zero_grad()
             if log_step % cfg.wandb_log_freq == 0:
                 history["loss_value"].append(loss_sum.item() / count)
+                if engine.head is not None:
+                    engine.head.check_fused_tail()      # (the host is synchronised here anyway: raises if a fused-tail grid barrier timed out)
                 history["learning_rate"].append(lr)
                 if discrete:
                     for k, v in token_metrics(batch, pred_ids).items():
