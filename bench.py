@@ -485,10 +485,39 @@ def main():
 
         ms_graph, pred_g = time_it(graph_once, n=50)
         assert torch.equal(pred_g, pred_e), "hipGraph replay must reproduce the eager actions bit for bit"
+        # roofline of the chunk ("B = 1 inference: report both"): M = S = 608 sits at the knee, so both floors are quoted.
+        # Per-kernel-family times of ONE eager chunk (HIP events on the launch stream; the two vision streams overlap, so they sum to more than
+        # the chunk's wall time) name the dominant kernel and its own rate.
+        ops.PROFILE = []
+        infer_once()
+        torch.cuda.synchronize()
+        ifam = {}
+        for family, e0, e1, fl in ops.PROFILE:
+            d = ifam.setdefault(family, [0, 0.0, 0.0])
+            d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fl
+        ops.PROFILE = None
+        flp1 = flops_per_sample(cfg, S, cfg.num_images, sel_rows=cfg.num_action_tokens)
+        w_bytes = 2.0 * (cfg.llm_layers * (4 * cfg.llm_dim ** 2 + 3 * cfg.llm_dim * cfg.llm_ff) + cfg.vision_dim * 4 * cfg.vision_dim + 4 * cfg.vision_dim * cfg.llm_dim +
+                         cfg.llm_dim ** 2 + sum((vc.depth - 1) * (4 * vc.dim ** 2 + 2 * vc.dim * vc.mlp_hidden) for vc in (cfg.dino, cfg.siglip)) +
+                         cfg.action_dim * cfg.llm_dim ** 2 + 2 * cfg.llm_dim ** 2)
+        igemm = {k: v for k, v in ifam.items() if k.startswith("gemm_nt")}
+        idom = max(igemm, key=lambda k: igemm[k][1])
+        inst1 = {"gemm_nt_t17": "gemm_nt_kernel<256,256,2,4>", "gemm_nt_t1": "gemm_nt_kernel<128,128,2,2>", "gemm_nt_t2": "gemm_nt_kernel<64,128,1,4>",
+                 "gemm_nt_t5": "gemm_nt_kernel<128,32,4,1>"}
+        infer_roofline = {
+            "mfma": {"flops_per_chunk": flp1["fwd"], "achieved": flp1["fwd"] / (ms_graph * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": flp1["fwd"] / (ms_graph * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "floor_ms": flp1["fwd"] / (PEAK_BF16_TFLOPS * 1e12) * 1e3},
+            "hbm": {"weight_bytes_per_chunk": w_bytes, "achieved": w_bytes / (ms_graph * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "frac": w_bytes / (ms_graph * 1e-3) / 1e9 / 8000.0, "floor_ms": w_bytes / 8e12 * 1e3},
+            "dominant_kernel": {"kernel": inst1.get(idom, idom) + " (incl. its hybrid / split-K reduce)", "launches": igemm[idom][0], "ms": igemm[idom][1],
+                                "achieved": igemm[idom][2] / (igemm[idom][1] * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                "frac": igemm[idom][2] / (igemm[idom][1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS},
+            "by_family_ms": {k: {"launches": v[0], "ms": v[1]} for k, v in sorted(ifam.items(), key=lambda kv: -kv[1][1])},
+            "profile": "profiles/r03_infer_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/infer_profile.py)"}
         infer = {"workload": "BASELINE.json configs[1]: OpenVLA-7B L1-regression inference, 2x224x224 images + proprio, bf16, batch 1 (one 8x7 action chunk per forward)",
                  "ms_per_chunk": ms_graph, "chunks_per_s": 1e3 / ms_graph, "actions_per_s": 1e3 / ms_graph * cfg.chunk,
                  "mode": "LoRA merged (W += 0.5 B A on device) + hipGraph replay",
-                 "ms_per_chunk_merged_eager": ms_merged, "ms_per_chunk_unmerged_eager": ms_lora}
+                 "ms_per_chunk_merged_eager": ms_merged, "ms_per_chunk_unmerged_eager": ms_lora, "roofline": infer_roofline}
 
     # ---- measured baselines, same process, same box, AFTER every timed region (rank 0, N = 1 only):
     #   B1  stock PyTorch-ROCm eager fine-tune step (the denominator of north_star's ">= 1.5x" target), B3 stock eager batch-1 chunk,

@@ -5,7 +5,9 @@
 #   build.sh packed   libovla_hip_packed.so: WITH the compiler's packed-FP32 VALU instructions (A/B measurement only)
 #
 # Packed FP32 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_mov_b32, which clang emits on gfx950 whenever two fp32 operations pair up) is switched
-# OFF for every file of the product library.  Root cause recorded in DESIGN.md "Run-to-run determinism" (tools/norm_bwd_wave_probe.py):
+# OFF for every file of the product library -- a WORKAROUND backed by a codegen A/B correlation, not a proven hardware erratum (a missing wait
+# state in the generated code or a timing-sensitive hazard would look the same; tools/determinism_check.py + the reproducibility GPU test gate
+# regressions).  Evidence recorded in DESIGN.md "Run-to-run determinism" (tools/norm_bwd_wave_probe.py):
 # a wave-per-row LayerNorm backward built with it dropped exactly one term of a per-lane running sum in lanes 48-63 of a few waves per
 # launch whenever another stream's kernels shared the CUs -- operands bit-identical (hashes of every loaded dword), the good run equal to a
 # host recomputation; the same source without packed FP32 never failed (3948 / 3368 differing rows vs 0 / 0, alternated), one stream never

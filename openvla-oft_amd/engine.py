@@ -42,11 +42,12 @@ _FUSE_ROPE_FWD = os.environ.get("OVLA_FUSE_ROPE_FWD", "1") == "1"
 _GROUP_TN = os.environ.get("OVLA_GROUP_TN", "1") == "1"   # ViT blocks: two neighbouring linears' LoRA weight-gradient problems in one launch (A/B switch)
 _FUSE_ACT, _FUSE_SWIGLU = _FUSE in ("act", "all"), _FUSE in ("swiglu", "all")
 # The action head's tail (two MLPResNet blocks, LayerNorm 2, fc2, L1 / MSE loss) as ONE launch for up to 64 rows (ovla_head_tail_fwd),
-# bit-identical to the unfused eight-launch sequence, so the switch is invisible in the numbers.  Measured: at 64 rows
-# (the fine-tune step) the two are equal within run-to-run noise (168.5 / 169.2 vs 168.1 / 168.7 ms/step, alternated); at 8 rows inside
-# the hipGraph-replayed inference chunk the fused kernel is 50 us SLOWER (15.75 / 15.83 vs 15.70 / 15.78 ms) -- four grid-wide barriers cost
-# more than the kernel boundaries they replace (a boundary is 1.5-1.9 us on this chip).  Default: fused for more than 16 rows, unfused below;
-# OVLA_FUSE_HEAD=0 / 1 forces one path everywhere.
+# bit-identical to the unfused eight-launch sequence.  OPT-IN (OVLA_FUSE_HEAD=1) since round 3: it never measured faster -- round 2: equal at 64
+# rows, 50 us slower per replayed inference chunk; round 3, after an 8-deep register ring on its weight / activation streams (kernel 148.8 ->
+# 114.6 us): whole head forward 219.8 vs 209.6 us unfused at 64 rows, 186.1 vs 169.6 us at 8 rows (tools/head_bench.py,
+# profiles/r03_head_bench.txt) -- four software grid barriers cost more than the eight kernel boundaries they replace, and a software grid
+# barrier needs every workgroup resident at once: the launch is refused otherwise, a timed-out spin poisons every output with NaN and sets a
+# sticky word that ActionHead.check_fused_tail() turns into an exception at the step's host sync.
 _FUSE_HEAD = {"0": False, "1": True}.get(os.environ.get("OVLA_FUSE_HEAD", "auto"), None)
 # OVLA_LORA_BWD=1: the LoRA backward's dt and dB from ONE pass over dy (csrc/lora_bwd.hip) instead of a skinny NT GEMM (dt) + TN GEMMs (dB, dA).
 # Built, parity-tested and measured in round 3 (tools/lora_bwd_bench.py, cold operands, M = 4864): 293.6 vs 272.4 us per decoder layer for the
@@ -629,7 +630,7 @@ class ActionHead:
         split = 8 if rows <= 256 else 1      # small-M weight stream: split K over the chip
         x, s1 = self.fc1.fwd(h0, act=ops.ACT_RELU, c_pre=z1, split_k=split)
         D = cfg.llm_dim
-        if (rows > 16 if _FUSE_HEAD is None else _FUSE_HEAD) and rows <= 64 and D % 64 == 0 and D // 16 <= 256 and (D // 16) % 4 == 0 and \
+        if bool(_FUSE_HEAD) and rows <= 64 and D % 64 == 0 and D // 16 <= 256 and (D // 16) % 4 == 0 and \
                 _lib.lib().ovla_head_tail_resident_blocks() >= D // 16:      # software grid barriers: only when the whole grid is co-resident
             # everything after fc1 -- both MLPResNet blocks, LayerNorm 2, fc2 and the loss -- is ONE launch (ovla_head_tail_fwd), bit-identical
             # to the unfused sequence below; its backward is the unfused one, fed from the tensors the kernel saves

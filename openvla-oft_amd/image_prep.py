@@ -103,7 +103,8 @@ def lanczos3_spans(in_size: int, out_size: int):
 
 def resize_image_for_policy(img: np.ndarray, resize_size, device=None, jpeg: bool = True) -> np.ndarray:
     """experiments/robot/openvla_utils.py:516-540: tf.image.encode_jpeg -> tf.io.decode_image (ovla_jpeg_roundtrip: libjpeg-turbo's baseline
-    4:2:0 quality-95 codec without the entropy coder, bit-identical to the library), then tf.image.resize(lanczos3, antialias=True) ->
+    4:2:0 quality-95 codec without the entropy coder, bit-identical to libjpeg-turbo's accurate-DCT (islow) path, fixture G12; PARITY UNPINNED
+    against TensorFlow itself, whose decode may use the fast IDCT: oracle/jpeg_oracle.py header), then tf.image.resize(lanczos3, antialias=True) ->
     round -> clip -> uint8 (ovla_image_resize), all on the device.  img uint8 [H, W, 3] -> uint8 [h, w, 3].  `jpeg=False` skips the codec (the
     training collator's resize of stored frames, rlds/obs_transforms.py:83, has none)."""
     import importlib

@@ -111,7 +111,11 @@ def run_diffusion_sampling(vla, action_head, noisy_action_projector, proprio_pro
                            current_action_mask, next_actions_mask, use_proprio, use_film) -> torch.Tensor:
     """finetune.py:454-540: reverse diffusion for the whole batch -- start from N(0, 1) noise, and for every DDIM timestep predict the
     noise from the action rows of the VLM's last hidden state and step x_t -> x_{t-1}.  The reference re-runs the vision backbone in every
-    step; its output does not depend on t, so here the projected patches of the first step are reused (same numbers, one tower pass)."""
+    step; its output does not depend on t, so here the projected patches of the first step are reused (same numbers, one tower pass).
+    METRICS-ONLY deviation from the reference's arithmetic (this function feeds the logged diffusion L1 numbers, never a gradient): the start
+    noise is drawn on the host and `scheduler.step` runs there in fp32 on the bf16-rounded sample, rounding to bf16 once per step, where the
+    reference keeps `curr_noisy_actions` / `noise_pred` in bf16 on the device throughout (finetune.py:490-540); `predict_action`'s diffusion
+    branch (modeling.py) is the deployment path and rounds where the reference does.  The per-step `.cpu()` is one host sync per DDIM step."""
     head, eng = action_head.module, vla.module.engine
     cfg = eng.cfg
     A = cfg.num_action_tokens

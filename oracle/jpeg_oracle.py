@@ -16,8 +16,12 @@ upsampling of the chroma planes (jdsample.c h2v2_fancy_upsample)  ->  YCbCr -> R
 The library's C sources are not under /root/reference (libjpeg-turbo is a TensorFlow dependency): this file restates their published
 algorithms.  PINNING: tests/golden/g12_jpeg_roundtrip.npz holds round trips produced by libjpeg-turbo itself (through Pillow, which links it,
 in the build container: tests/golden/make_golden_jpeg.py); tests/test_oracle_pins.py requires this restatement to reproduce them bit for bit.
-Against TensorFlow itself (absent): PARITY UNPINNED -- in particular that `decode_image` decodes with islow (its DecodeJpeg sibling defaults to
-the fast integer DCT) is read from the TF 2.15 sources' structure, not verified by running TF."""
+Against TensorFlow itself (absent): PARITY UNPINNED.  In particular the DECODE leg's IDCT is an open point: this file models it as islow
+(JDCT_DEFAULT), but TensorFlow's DecodeImage / DecodeJpeg ops may select the fast integer IDCT (JDCT_IFAST, jidctfst.c) -- a reviewer's
+recollection of decode_image_op.cc says they do; neither reading can be checked here (no TensorFlow, turbojpeg, simplejpeg, cv2 or imageio in
+the image, and Pillow exposes islow only).  If TF decodes with ifast, some pixels of the round trip differ from this model by 1-2 LSB before the
+lanczos resize.  What G12 pins is therefore the libjpeg-turbo islow codec (every stage TF and this model share: colour conversion, chroma
+subsampling, FDCT, quantisation tables, fancy upsampling), NOT bit-identity with the reference's TensorFlow round trip."""
 from __future__ import annotations
 
 import numpy as np
