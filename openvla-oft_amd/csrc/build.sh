@@ -2,6 +2,7 @@
 # Builds libovla_hip.so (gfx950 only) in-tree next to the sources.  hipcc cross-compiles without a GPU.
 #   build.sh          the product library
 #   build.sh ablate   libovla_hip_ablate.so: the same sources with -DOVLA_GEMM_ABLATE (timing ablations of gemm_nt, tools/gemm_ablate.py)
+#   build.sh exp      libovla_hip_exp.so: the same sources with $OVLA_EXP_FLAGS (A/B of compile-time experiments; load with OVLA_LIB_NAME)
 #   build.sh packed   libovla_hip_packed.so: WITH the compiler's packed-FP32 VALU instructions (A/B measurement only)
 #
 # Packed FP32 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_mov_b32, which clang emits on gfx950 whenever two fp32 operations pair up) is switched
@@ -21,10 +22,11 @@ OUT=../libovla_hip.so; EXTRA=""; BUILD=../_build
 SRCS="$(ls *.hip | LC_ALL=C sort | tr '\n' ' ')"
 NOPK="$SRCS"
 if [ "$MODE" = "ablate" ]; then OUT=../libovla_hip_ablate.so; EXTRA="-DOVLA_GEMM_ABLATE"; BUILD=../_build_ablate; fi
+if [ "$MODE" = "exp" ]; then OUT=../libovla_hip_exp.so; EXTRA="${OVLA_EXP_FLAGS:-}"; BUILD=../_build_exp; fi   # same-call A/B of a compile-time experiment (OVLA_EXP_FLAGS="-DOVLA_GEMM_SPREAD2")
 if [ "$MODE" = "packed" ]; then OUT=../libovla_hip_packed.so; BUILD=../_build_packed; NOPK=""; fi
 NOPK_FLAGS="-Xclang -target-feature -Xclang -packed-fp32-ops"   # (the host pass prints "not a recognized feature ... ignoring": filtered below)
 HASH=$(cat $(ls *.hip *.h | LC_ALL=C sort) build.sh ../../include/ovla.h | sha256sum | cut -c1-32)
-STAMP="$HASH-$MODE"
+STAMP="$HASH-$MODE-${OVLA_EXP_FLAGS:-}"
 if [ -f "$OUT" ] && [ -f "$OUT.hash" ] && [ "$(cat "$OUT.hash")" = "$STAMP" ]; then echo "$(basename $OUT) up to date ($HASH)"; exit 0; fi
 mkdir -p $BUILD
 pids=()

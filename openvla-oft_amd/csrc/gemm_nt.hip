@@ -52,7 +52,7 @@ struct GemmParams {
   const bf16_bits *rope_cos, *rope_sin; int rope_S, rope_cols;           // forward RoPE on columns [0, rope_cols), head_dim 128
   int fast_epi;  // host: no FiLM / backward epilogue / RoPE and 16-byte aligned operands -> the unrolled read-back path applies
   int fast_swiglu_bwd;  // host: dact_mode 2 with 16-byte aligned [M, 2N] operands and nothing else in the epilogue -> SwiGLU' in the unrolled read-back
-  int dbg;  // timing ablations, compiled in ONLY with -DOVLA_GEMM_ABLATE (build.sh ablate -> libovla_hip_ablate.so, tools/gemm_ablate.py): bit0 = stage only the first two K tiles, bit1 = read fragments once, bit2 = every workgroup stages tile (0,0): all L2 hits, bit3 = no epilogue, bit4 = epilogue without its stores, bit5 = nontemporal stores, bit6 = force the LDS-staged epilogue
+  int dbg;  // timing ablations, compiled in ONLY with -DOVLA_GEMM_ABLATE (build.sh ablate -> libovla_hip_ablate.so, tools/gemm_ablate.py): bit0 = stage only the first two K tiles, bit1 = read fragments once, bit2 = every workgroup stages tile (0,0): all L2 hits, bit3 = no epilogue, bit4 = epilogue without its stores, bit5 = nontemporal stores, bit6 = force the LDS-staged epilogue, bit7 / bit8 / bit9 = no (A and B) / B / A fragment reads after the first K tile
   int full_tiles, rem_tiles, rem_splits;  // hybrid schedule: tiles >= full_tiles are split rem_splits ways along K
 };
 
@@ -115,6 +115,13 @@ OVLA_DEV bf16x8_bits lds_frag(const bf16_bits* tile, int row, int chunk) {
   const int phys = chunk ^ ((row >> 1) & 7);
   return *reinterpret_cast<const bf16x8_bits*>(tile + row * BK + phys * 8);
 }
+#ifdef OVLA_GEMM_ABLATE
+// timing ablations on the fragment reads (bit7: no A or B fragment read after the first K tile; bit8: no B fragment read; bit9: no A fragment read):
+// what the LDS read traffic costs the main loop
+#define OVLA_FRAG(var, expr, bits) do { if (!(p.dbg & (bits)) || t == t_begin) var = (expr); } while (0)
+#else
+#define OVLA_FRAG(var, expr, bits) var = (expr)
+#endif
 
 // Epilogue on 4 consecutive columns n..n+3 of row m.  Every step rounds to bf16, as the reference's separate ops do.
 OVLA_DEV void epilogue_store(const GemmParams& p, int m, int n, f32x4 v) {
@@ -326,6 +333,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   // (`SPREAD` loop); the K tail and the LoRA K-extension tiles keep the simple stage-after-barrier scheme.
   constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW, PP = PA + PB;
   constexpr int PPS = (PP + MT - 1) / MT;
+  // SPREAD2 (OVLA_GEMM_SPREAD2, experiment): when the pieces are no more than the m-tiles (256x256 on 8 waves: 8 and 8), deal ONE piece to every
+  // SECOND of the 2 MT row slots of a K tile instead of one to each of the first MT: 8 MFMAs (128 matrix-pipe cycles) between two pieces
+#ifdef OVLA_GEMM_SPREAD2
+  constexpr bool SPREAD2 = (PP <= MT);
+#else
+  constexpr bool SPREAD2 = false;
+#endif
+  auto n_pieces_at = [](int slot) constexpr -> int {   // pieces issued at row slot `slot` (0 .. 2 MT - 1)
+    if (SPREAD2) return (slot % 2 == 0 && slot / 2 < PP) ? 1 : 0;
+    if (slot >= MT) return 0;
+    return ((slot + 1) * PPS <= PP) ? PPS : ((slot * PPS < PP) ? PP - slot * PPS : 0);
+  };
   auto tile_body = [&](const int t, auto spread_tag) {
     constexpr bool SPREAD = decltype(spread_tag)::value;
     const int buf = (t - t_begin) & 1;
@@ -342,8 +361,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     const char* gB = reinterpret_cast<const char*>(p.B) + (int64_t)(t + 1) * (BK * 2);
     auto pieces = [&](auto slot_tag) {
       constexpr int SLOT = decltype(slot_tag)::value;
+      constexpr int Q0 = SPREAD2 ? SLOT / 2 : SLOT * PPS, Q1 = SPREAD2 ? (SLOT % 2 == 0 ? SLOT / 2 + 1 : SLOT / 2) : (SLOT + 1) * PPS;
 #pragma unroll
-      for (int q = SLOT * PPS; q < (SLOT + 1) * PPS && q < PP; ++q) {
+      for (int q = Q0; q < Q1 && q < PP; ++q) {
         if (q < PA)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + offA[q < PA ? q : 0]),
                                            (__attribute__((address_space(3))) void*)(nA + (wave * PA + q) * 8 * BK), 16, 0, 0);
@@ -352,10 +372,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
                                            (__attribute__((address_space(3))) void*)(nB + (wave * PB + (q - PA)) * 8 * BK), 16, 0, 0);
       }
     };
-    constexpr int NP0 = PP < PPS ? PP : PPS;
+    constexpr int NP0 = n_pieces_at(0);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) b0[j] = lds_frag(sB, bcol[j] + brl, cq);
-    bf16x8_bits a_cur = lds_frag(sA, arow, cq);
+    for (int j = 0; j < NT; ++j) OVLA_FRAG(b0[j], lds_frag(sB, bcol[j] + brl, cq), 128 | 256);
+    bf16x8_bits a_cur = a_def;
+    OVLA_FRAG(a_cur, lds_frag(sA, arow, cq), 128 | 512);
     if constexpr (SPREAD) pieces(std::integral_constant<int, 0>{});
     __builtin_amdgcn_s_setprio(1);
     // deferred last row of the previous tile (zeros on the first pass)
@@ -368,13 +389,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     auto row = [&](auto r_tag) {
       constexpr int r = decltype(r_tag)::value;
       constexpr int sub = r / MT, i = r % MT;
-      bf16x8_bits a_nxt = lds_frag(sA, arow + ((r + 1) % MT) * 16, ((r + 1) / MT) * 4 + cq);
+      bf16x8_bits a_nxt = a_cur;
+      OVLA_FRAG(a_nxt, lds_frag(sA, arow + ((r + 1) % MT) * 16, ((r + 1) / MT) * 4 + cq), 128 | 512);
       if constexpr (sub == 0) {
 #pragma unroll
         for (int jj = 0; jj < BPR; ++jj)
-          if (i * BPR + jj < NT) b1[i * BPR + jj] = lds_frag(sB, bcol[i * BPR + jj] + brl, 4 + cq);
+          if (i * BPR + jj < NT) OVLA_FRAG(b1[i * BPR + jj], lds_frag(sB, bcol[i * BPR + jj] + brl, 4 + cq), 128 | 256);
       }
-      constexpr int NPR = (r + 1 < MT) ? (((r + 2) * PPS <= PP) ? PPS : (((r + 1) * PPS < PP) ? PP - (r + 1) * PPS : 0)) : 0;
+      constexpr int NPR = n_pieces_at(r + 1);
       if constexpr (SPREAD && NPR > 0) pieces(std::integral_constant<int, r + 1>{});
 #pragma unroll
       for (int j = 0; j < NT; ++j)
