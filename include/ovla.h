@@ -93,6 +93,16 @@ typedef struct {
   int32_t rope_S, rope_cols;                   /* row % rope_S) applied to output columns [0, rope_cols) -- the q | k heads of a fused
                                                   q|k|v projection (modeling_llama apply_rotary_pos_emb).  Excludes the other epilogues;
                                                   fused into the 256x256 config's epilogue, otherwise one extra ovla_rope launch. */
+  /* RMSNorm folded around the GEMM (the decoder's input_layernorm / post_attention_layernorm, HF LlamaRMSNorm at modeling_prismatic.py:632-643,
+   * on the merged inference path; the norm WEIGHT is folded into B offline, B' = bf16(B * w[k])):
+   *   producer side  rowsq_out [M, N/64] fp32: sum of squares of every 64-column group of the bf16 OUTPUT row (plain stores, one writer per
+   *                  slot: summed later in slot order -- deterministic);
+   *   consumer side  rowscale_part [M, rowscale_slots] fp32 = the producer's rowsq_out for this GEMM's A operand (rowscale_slots * 64 = K):
+   *                  C = epilogue(rstd[m] * alpha * acc), rstd[m] = rsqrt(sum(slots) / K + rowscale_eps); rowscale_r [M] fp32 scratch
+   *                  receives rstd (the hybrid-remainder reduce reads it).
+   * Supported on the 128x128 tile only (tile 1 / 101, what the batch-1 shapes M <= ~1k resolve to); any other schedule is an error. */
+  float* rowsq_out;
+  const float* rowscale_part; int32_t rowscale_slots; float rowscale_eps; float* rowscale_r;
   void* workspace;               /* fp32 scratch: [split_k, M, N] when split_k > 1; also enables the auto schedules */
   int64_t workspace_bytes;       /* (hybrid remainder split, skinny-N split-K) when tile == 0; may be NULL/0 */
 } ovla_gemm_args;
@@ -357,6 +367,10 @@ typedef struct {
   int32_t ignore_index, action_token_begin, action_dim;
 } ovla_assemble_args;
 int ovla_assemble_multimodal(const ovla_assemble_args* a, void* stream);
+
+/* Per-row sums of squares of every 64-column group: out[m, j] = sum x[m, 64 j .. 64 j + 63]^2 (fp32, [rows, dim / 64]) -- the RMSNorm-fold
+ * input of the FIRST decoder layer (ovla_gemm_args.rowscale_part); later layers get theirs from the producing GEMM's epilogue (rowsq_out). */
+int ovla_row_sumsq(const void* x, int64_t ld, float* out, int32_t rows, int32_t dim, void* stream);
 
 /* dst[i, :] = src[index[i], :]  /  scatter-add backward  */
 typedef struct { const void* src; const int32_t* index; void* dst; int32_t n, dim; int64_t src_ld, dst_ld; int32_t scatter_add; } ovla_gather_rows_args;

@@ -1351,6 +1351,31 @@ extern "C" int ovla_assemble_multimodal(const ovla_assemble_args* a, void* strea
   OVLA_CHECK_LAUNCH("ovla_assemble_multimodal");
   return OVLA_OK;
 }
+namespace {
+// one wave per row; lane j owns slot j, j + 64, ... (64 bf16 = 128 bytes = 8 16-byte loads per slot)
+__global__ __launch_bounds__(256) void row_sumsq_kernel(const bf16_bits* __restrict__ x, int64_t ld, float* __restrict__ out, int rows, int slots) {
+  const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  for (int j = lane; j < slots; j += 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float f[8];
+      load8(x + (int64_t)m * ld + j * 64 + c * 8, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = __builtin_fmaf(f[e], f[e], s);
+    }
+    out[(int64_t)m * slots + j] = s;
+  }
+}
+}  // namespace
+extern "C" int ovla_row_sumsq(const void* x, int64_t ld, float* out, int32_t rows, int32_t dim, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  OVLA_REQUIRE(x && out && rows > 0 && dim > 0 && (dim % 64) == 0 && (ld % 8) == 0 && ld >= dim && aligned16(x), "ovla_row_sumsq: rows=%d dim=%d (multiple of 64) ld=%lld", rows, dim, (long long)ld);
+  hipLaunchKernelGGL(row_sumsq_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, (const bf16_bits*)x, ld, out, rows, dim / 64);
+  OVLA_CHECK_LAUNCH("ovla_row_sumsq");
+  return OVLA_OK;
+}
 extern "C" int ovla_gather_rows(const ovla_gather_rows_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   OVLA_REQUIRE(a && a->src && a->index && a->dst && a->n > 0 && a->dim > 0 && (a->dim % 8) == 0, "ovla_gather_rows: bad arguments");

@@ -54,7 +54,18 @@ struct GemmParams {
   int fast_swiglu_bwd;  // host: dact_mode 2 with 16-byte aligned [M, 2N] operands and nothing else in the epilogue -> SwiGLU' in the unrolled read-back
   int dbg;  // timing ablations, compiled in ONLY with -DOVLA_GEMM_ABLATE (build.sh ablate -> libovla_hip_ablate.so, tools/gemm_ablate.py): bit0 = stage only the first two K tiles, bit1 = read fragments once, bit2 = every workgroup stages tile (0,0): all L2 hits, bit3 = no epilogue, bit4 = epilogue without its stores, bit5 = nontemporal stores, bit6 = force the LDS-staged epilogue, bit7 / bit8 / bit9 = no (A and B) / B / A fragment reads after the first K tile
   int full_tiles, rem_tiles, rem_splits;  // hybrid schedule: tiles >= full_tiles are split rem_splits ways along K
+  // RMSNorm fold (ovla.h): producer writes per-row sums of squares of its output's 64-column groups; consumer scales the accumulator by rstd[m]
+  float* rowsq_out;
+  const float* rowscale_part; int rowscale_slots; float rowscale_eps; float* rowscale_r;
 };
+
+// sum of squares of 4 bf16-rounded outputs, reduced over the 16 lanes that hold one row's 64-column group (lanes aligned to 16)
+OVLA_DEV float rowsq16(f32x4 v) {
+  float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+  return s;
+}
 
 // Stage ROWS x 64 bf16 of a row-major [rows, ld] matrix into an LDS tile (swizzled 128-byte rows) with LDS-DMA.
 template <int ROWS, int NW>
@@ -124,7 +135,7 @@ OVLA_DEV bf16x8_bits lds_frag(const bf16_bits* tile, int row, int chunk) {
 #endif
 
 // Epilogue on 4 consecutive columns n..n+3 of row m.  Every step rounds to bf16, as the reference's separate ops do.
-OVLA_DEV void epilogue_store(const GemmParams& p, int m, int n, f32x4 v) {
+OVLA_DEV f32x4 epilogue_store(const GemmParams& p, int m, int n, f32x4 v) {   // returns the stored (bf16-rounded) values
   v *= p.alpha;
   if (p.bias) {
     const bf16x4_bits b = *reinterpret_cast<const bf16x4_bits*>(p.bias + n);
@@ -189,13 +200,14 @@ OVLA_DEV void epilogue_store(const GemmParams& p, int m, int n, f32x4 v) {
   }
   bf16x4_bits o;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = (short)f2bf(v[j]);
-  if (OVLA_DBG(16) && v[0] != 123.456f) return;            // timing ablation: the whole epilogue except the store
+  for (int j = 0; j < 4; ++j) { o[j] = (short)f2bf(v[j]); v[j] = bf2f((bf16_bits)o[j]); }
+  if (OVLA_DBG(16) && v[0] != 123.456f) return v;          // timing ablation: the whole epilogue except the store
   if (OVLA_DBG(32)) {                                          // timing ablation: write-through store that does not stay in this XCD's L2
     __builtin_nontemporal_store(o, reinterpret_cast<bf16x4_bits*>(p.C + (int64_t)m * p.ldc + n));
-    return;
+    return v;
   }
   *reinterpret_cast<bf16x4_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
+  return v;
 }
 
 // RoPE epilogue (head_dim 128): v = this lane's 4 accumulator sums at columns n..n+3 of row m, vp = the sums at the rotation
@@ -284,6 +296,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // RMSNorm fold, consumer side (128x128 config only): rstd of this tile's 128 rows from the producer's per-64-column sums of squares, into
+  // LDS behind the K-tile buffers / epilogue slabs.  Two lanes per row, 8 16-byte loads each; they are in flight with the first K tile's
+  // LDS-DMA and waited for by the same vmcnt(0), and the K loop's first barrier publishes s_rstd: the prologue costs no round trip of its own.
+  constexpr bool NORMFOLD = (BM == 128 && BN == 128 && WM == 2 && WN == 2);
+  constexpr size_t NF_KB = (size_t)2 * TILE_ELEMS * sizeof(bf16_bits), NF_EB = (size_t)NW * (MT < 2 ? MT : 2) * 16 * (WTN + 4) * sizeof(float);
+  float* s_rstd = reinterpret_cast<float*>(smem_raw + (NF_KB > NF_EB ? NF_KB : NF_EB));
+  bool rowscale = false;
+  if constexpr (NORMFOLD) {
+    rowscale = p.rowscale_part != nullptr;
+    if (rowscale) {
+      const int row = tid >> 1, half = tid & 1, m = m0 + row;
+      float ssum = 0.f;
+      if (m < p.M) {
+        const int per = p.rowscale_slots >> 1;             // slots this lane adds, in slot order (rowscale_slots % 8 == 0: host-checked)
+        const float* src = p.rowscale_part + (int64_t)m * p.rowscale_slots + half * per;
+        for (int j = 0; j < per; j += 4) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(src + j);
+          ssum += q[0]; ssum += q[1]; ssum += q[2]; ssum += q[3];
+        }
+      }
+      ssum += __shfl_xor(ssum, 1, 64);
+      const float r = m < p.M ? rsqrtf(ssum / (float)(p.rowscale_slots * 64) + p.rowscale_eps) : 0.f;
+      s_rstd[row] = r;
+      if (half == 0 && m < p.M && tn == 0 && split == 0 && p.rowscale_r) p.rowscale_r[m] = r;   // for the hybrid-remainder reduce kernel
+    }
+  }
+
   uint32_t offA[BM / 8 / NW], offB[BN / 8 / NW];
   stage_offsets<BM, NW>(offA, p.lda, OVLA_DBG(4) ? 0 : m0, p.M - 1, wave, lane);
   stage_offsets<BN, NW>(offB, p.ldb, OVLA_DBG(4) ? 0 : n0, p.N - 1, wave, lane);
@@ -317,7 +356,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   // partner of tile j is tile j ^ 2 of the SAME wave, 32 floats away in the same row of its own epilogue slab -- the rotation needs no
   // other wave's data and no extra barrier, and 8 consecutive slab columns are still 8 consecutive output columns (16-byte stores).
   bool rope_tile = false;
-  if constexpr (WN == 4 && WTN == 64 && BN == 256) rope_tile = p.rope_cos != nullptr && n0 < p.rope_cols;
+  // (the same map serves the 128x128 tile on 2x2 waves: one head per tile, wave wn takes 32 wn + [0, 32) and + 64)
+  constexpr bool ROPE_LAYOUT = WTN == 64 && ((WN == 4 && BN == 256) || (WN == 2 && BN == 128));
+  if constexpr (ROPE_LAYOUT) rope_tile = p.rope_cos != nullptr && n0 < p.rope_cols;
   int bcol[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) bcol[j] = rope_tile ? ((wn >> 1) * 128 + (wn & 1) * 32 + (j & 1) * 16 + (j >> 1) * 64) : (wn * WTN + j * 16);
@@ -505,8 +546,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     }
     return;
   }
-  if constexpr (WN == 4 && WTN == 64 && BN == 256) {
-    if (rope_tile) {   // RoPE in the unrolled read-back (host guarantees an interior tile, alpha only, 16-byte aligned tables)
+  if constexpr (ROPE_LAYOUT) {
+    if (rope_tile) {   // RoPE in the unrolled read-back (host guarantees whole column tiles, alpha only, 16-byte aligned tables; rows past M are skipped)
       constexpr int STEPS = RM * 16 * 8 / 64;
       const int mbase = m0 + wm * WTM, nhead = n0 + (wn >> 1) * 128, chalf = (wn & 1) * 32;
       __syncthreads();
@@ -528,17 +569,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
           const int cin = chalf + ((c8 & 3) << 3);                         // column within the 64-wide half of the head
           const bool upper = c8 >= 4;
           const int m = mbase + round * RM * 16 + row, n = nhead + cin + (upper ? 64 : 0);
+          float ra = p.alpha;
+          if constexpr (NORMFOLD) { if (rowscale) ra *= s_rstd[wm * WTM + round * RM * 16 + row]; }
           const int pos = m % p.rope_S;
           const bf16x8_bits cs = *reinterpret_cast<const bf16x8_bits*>(p.rope_cos + (int64_t)pos * 64 + cin);
           const bf16x8_bits sn = *reinterpret_cast<const bf16x8_bits*>(p.rope_sin + (int64_t)pos * 64 + cin);
           bf16x8_bits o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {    // rope_kernel's arithmetic on y = bf16(acc): lo' = bf16(a c) + bf16(-b s), hi' = bf16(b c) + bf16(a s)
-            const float x = bfround((e < 4 ? xlo[e] : xhi[e - 4]) * p.alpha), y = bfround((e < 4 ? ylo[e] : yhi[e - 4]) * p.alpha);
+            const float x = bfround((e < 4 ? xlo[e] : xhi[e - 4]) * ra), y = bfround((e < 4 ? ylo[e] : yhi[e - 4]) * ra);
             const float cc = bf2f((bf16_bits)cs[e]), sv = bf2f((bf16_bits)sn[e]);
             o[e] = (short)f2bf(upper ? bfround(x * cc) + bfround(y * sv) : bfround(x * cc) + bfround(-y * sv));
           }
-          *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
+          if (m < p.M) *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
@@ -576,8 +619,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
         const int idx = st * 64 + lane, row = idx / OCT, c8 = idx % OCT;
         const int m = mbase + round * RM * 16 + row, n = nbase + c8 * 8;
         float x[8];
+        float ra = p.alpha;
+        if constexpr (NORMFOLD) { if (rowscale) ra *= s_rstd[wm * WTM + round * RM * 16 + row]; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { x[e] = lo[s2][e] * p.alpha; x[4 + e] = hi[s2][e] * p.alpha; }
+        for (int e = 0; e < 4; ++e) { x[e] = lo[s2][e] * ra; x[4 + e] = hi[s2][e] * ra; }
         if (p.bias) {
           const bf16x8_bits b8 = *reinterpret_cast<const bf16x8_bits*>(p.bias + n);
 #pragma unroll
@@ -610,6 +655,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
         bf16x8_bits o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(x[e]);
+        if constexpr (NORMFOLD) {
+          if (p.rowsq_out) {   // producer side: this wave's 64-column group of row m = 8 lanes x 8 stored values (x is already bf16-rounded here)
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = bf2f((bf16_bits)o[e]); sq += f * f; }
+            sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+            if (c8 == 0) p.rowsq_out[(int64_t)m * (p.N >> 6) + (nbase >> 6)] = sq;
+          }
+        }
         if (OVLA_DBG(32)) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n));
         else *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
       }
@@ -641,6 +695,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
           if (m < p.M) rope_store(p, m, n, v, vp);
           continue;
         }
+      }
+      if constexpr (NORMFOLD) {
+        // (WTN = 64: a slab row is one 64-column group, read back by 16 consecutive lanes; the host guarantees N % 64 == 0, so the 16 lanes of
+        // a row are inside or outside the matrix together and the shuffles run in uniform control flow)
+        f32x4 vs = v;
+        if (rowscale) vs *= s_rstd[wm * WTM + round * RM * 16 + row];
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+        const bool inside = m < p.M && n < p.N;
+        if (inside) st = epilogue_store(p, m, n, vs);
+        if (p.rowsq_out) {
+          const float sq = rowsq16(st);
+          if (inside && c4 == 0) p.rowsq_out[(int64_t)m * (p.N >> 6) + (n >> 6)] = sq;
+        }
+        continue;
       }
       if (m < p.M && n < p.N) epilogue_store(p, m, n, v);
     }
@@ -961,13 +1029,18 @@ __global__ __launch_bounds__(256) void gemm_hybrid_reduce_kernel(const GemmParam
     if (m >= p.M || n >= p.N) continue;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     for (int sidx = 0; sidx < p.rem_splits; ++sidx) v += *reinterpret_cast<const f32x4*>(slab0 + (int64_t)sidx * (BM * BN) + lm * BN + ln);
+    const float rs = p.rowscale_part ? p.rowscale_r[m] : 1.f;      // RMSNorm fold, consumer side: rstd written by the GEMM kernel's prologue
     if (p.rope_cos && n < p.rope_cols) {   // BN is a multiple of 128 here (launch_cfg checks): the partner quad is in the same tile
       f32x4 vp = {0.f, 0.f, 0.f, 0.f};
       for (int sidx = 0; sidx < p.rem_splits; ++sidx) vp += *reinterpret_cast<const f32x4*>(slab0 + (int64_t)sidx * (BM * BN) + lm * BN + (ln ^ 64));
-      rope_store(p, m, n, v, vp);
+      rope_store(p, m, n, v * rs, vp * rs);
       continue;
     }
-    epilogue_store(p, m, n, v);
+    const f32x4 st = epilogue_store(p, m, n, v * rs);
+    if (p.rowsq_out) {   // producer side: 16 consecutive threads hold one row's 64-column group (rows / columns outside the matrix skipped above, whole groups at a time)
+      const float sq = rowsq16(st);
+      if (((ln >> 2) & 15) == 0) p.rowsq_out[(int64_t)m * (p.N >> 6) + (n >> 6)] = sq;
+    }
   }
 }
 
@@ -1057,6 +1130,11 @@ int launch_cfg(GemmParams& p, hipStream_t stream, int64_t ws_bytes = 0, bool hyb
   size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16_bits);
   const size_t epi = (size_t)WM * WN * 32 * (BN / WN + 4) * sizeof(float);   // epilogue staging slabs reuse the same LDS
   if (epi > lds) lds = epi;
+  if (BM == 128 && BN == 128) lds += BM * sizeof(float);                       // s_rstd of the RMSNorm fold, behind both
+  if ((p.rowsq_out || p.rowscale_part) && !(BM == 128 && BN == 128 && WM == 2 && WN == 2)) {
+    ovla_set_error("ovla_gemm_bf16: the RMSNorm fold (rowsq_out / rowscale_part) runs on the 128x128 tile only; this problem resolved to %dx%d", BM, BN);
+    return OVLA_EINVAL;
+  }
   auto kern = gemm_nt_kernel<BM, BN, WM, WN>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1195,6 +1273,12 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
   p.dact_src = (const bf16_bits*)a->dact_src; p.ld_dact = a->ld_dact; p.dact_mode = a->dact_src ? a->dact_mode : 0; p.dact_act = a->dact_act;
   p.rope_cos = nullptr; p.rope_sin = nullptr; p.rope_S = a->rope_S; p.rope_cols = a->rope_cols;   // enabled below for the config that fuses it
+  p.rowsq_out = a->rowsq_out; p.rowscale_part = a->rowscale_part; p.rowscale_slots = a->rowscale_slots; p.rowscale_eps = a->rowscale_eps; p.rowscale_r = a->rowscale_r;
+  if (a->rowsq_out) OVLA_REQUIRE((a->N % 64) == 0 && a->split_k <= 1 && !a->dact_src && !a->film_gamma && (((uintptr_t)a->rowsq_out) & 3) == 0,
+                                 "ovla_gemm_bf16: rowsq_out needs N %% 64 == 0, no split_k and a forward epilogue");
+  if (a->rowscale_part)
+    OVLA_REQUIRE(a->rowscale_slots > 0 && (a->rowscale_slots % 8) == 0 && a->rowscale_slots * 64 == a->K && a->rowscale_r && aligned16(a->rowscale_part) && a->split_k <= 1 &&
+                     a->a_group_n == 0, "ovla_gemm_bf16: rowscale_part needs rowscale_slots * 64 == K (multiple of 8 slots), a rowscale_r scratch and no split_k");
   p.T1 = cdiv(p.K, BK); p.T2 = p.K2 > 0 ? cdiv(p.K2, BK) : 0;
   if (p.split_k > p.T1 + p.T2) p.split_k = p.T1 + p.T2;
   p.full_tiles = 0; p.rem_tiles = 0; p.rem_splits = 1;
@@ -1247,7 +1331,10 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     // rotation partners (gemm_nt_kernel: rope_tile): M, N and rope_cols multiples of 256, nothing but alpha in the epilogue
     const bool fused17 = (tile == 17 || tile == 117) && p.split_k <= 1 && rope_plain && (p.M % 256) == 0 && (p.N % 256) == 0 && (a->rope_cols % 256) == 0 &&
                          (((uintptr_t)a->rope_cos | (uintptr_t)a->rope_sin | (uintptr_t)a->C) & 15) == 0 && (a->ldc % 8) == 0;
-    const bool fused = ((tile == 16 || tile == 116) && p.split_k <= 1) || fused17;
+    // ... and on the 128x128 tile (2x2 waves; batch-1 inference, M = 608): one head per column tile, any M (edge rows are skipped in the read-back)
+    const bool fused1 = (tile == 1 || tile == 101) && p.split_k <= 1 && rope_plain && (p.N % 128) == 0 && (a->rope_cols % 128) == 0 &&
+                        (((uintptr_t)a->rope_cos | (uintptr_t)a->rope_sin | (uintptr_t)a->C) & 15) == 0 && (a->ldc % 8) == 0;
+    const bool fused = ((tile == 16 || tile == 116) && p.split_k <= 1) || fused17 || fused1;
     if (fused) {
       p.rope_cos = (const bf16_bits*)a->rope_cos; p.rope_sin = (const bf16_bits*)a->rope_sin;
     } else {

@@ -49,6 +49,8 @@ _FUSE_ACT, _FUSE_SWIGLU = _FUSE in ("act", "all"), _FUSE in ("swiglu", "all")
 # barrier needs every workgroup resident at once: the launch is refused otherwise, a timed-out spin poisons every output with NaN and sets a
 # sticky word that ActionHead.check_fused_tail() turns into an exception at the step's host sync.
 _FUSE_HEAD = {"0": False, "1": True}.get(os.environ.get("OVLA_FUSE_HEAD", "auto"), None)
+# OVLA_FOLD_RMSNORM=0: keep the decoder's RMSNorms as their own launches on the merged inference path (A/B switch of LlamaStack.fold_norms).
+_FOLD_RMSNORM = os.environ.get("OVLA_FOLD_RMSNORM", "1") != "0"
 # OVLA_LORA_BWD=1: the LoRA backward's dt and dB from ONE pass over dy (csrc/lora_bwd.hip) instead of a skinny NT GEMM (dt) + TN GEMMs (dB, dA).
 # Built, parity-tested and measured in round 3 (tools/lora_bwd_bench.py, cold operands, M = 4864): 293.6 vs 272.4 us per decoder layer for the
 # three-kernel path -- reading dy once saves 0.4 GB per layer, but a 2-D (rows x 256-column) decomposition pays it back as fp32 partial-dt slabs
@@ -507,6 +509,33 @@ class LlamaStack:
         for l in self.layers:
             yield from (l["qkv"], l["o"], l["gu"], l["down"])
 
+    # -- RMSNorm folded around the projections (inference on adapter-free weights) ------------------------------------------------------
+    def fold_norms(self):
+        """`north_star`'s "fused RMSNorm + RoPE + QKV" on the inference path (HF LlamaDecoderLayer: input_layernorm -> q|k|v, post_attention_layernorm
+        -> gate|up; call site modeling_prismatic.py:901-912).  y = (w * x * rstd) W^T = rstd * (x (W w)^T): the norm WEIGHT is folded into a second
+        copy of the frozen projection weight (columns scaled, rounded to bf16 once, offline), the per-row sum of squares comes out of the PRODUCING
+        GEMM's epilogue (o_proj / down_proj with the residual add: ovla_gemm_args.rowsq_out; the first layer's from ovla_row_sumsq) and rstd scales
+        the accumulator in the consuming GEMM's epilogue, before the RoPE rotation (rowscale_part) -- no norm kernel, no normalised activations in
+        HBM.  Needs weights without live adapters (merged or adapter-free) and costs a second copy of the q|k|v and gate|up weights (+9 GB at 7B).
+        The rounding points move (the reference rounds x * rstd and w * (.) to bf16 before the GEMM): tests/test_fullsize_e2e_gpu.py bounds the delta."""
+        for l in self.layers:
+            for key, nk in (("qkv", "n1"), ("gu", "n2")):
+                lin = l[key]
+                if lin.has_lora and not getattr(lin, "merged", False):
+                    raise RuntimeError("fold_norms: the decoder still carries live LoRA adapters (merge_lora() first)")
+                l[key + "_n"] = ops.colscale(lin.W, l[nk])          # bf16(W[n, k] * w[k])
+        self.folded = True
+        self._fold_plan = {}
+
+    def _fold_ok(self, M: int) -> bool:
+        """The fold runs in the 128x128 GEMM configuration only (ovla.h): usable when all four projections of an M-row forward resolve to it."""
+        ok = self._fold_plan.get(M)
+        if ok is None:
+            D, F = self.cfg.llm_dim, self.cfg.llm_ff
+            ok = D % 512 == 0 and self.hd == 128 and all(ops.gemm_plan(M, n, k)[0] == 1 for n, k in ((3 * D, D), (D, D), (2 * F, D), (D, F)))
+            self._fold_plan[M] = ok
+        return ok
+
     def _tables(self, S, device):
         if self.cos is None or self.cos.shape[0] < S:
             n = max(S, self.cfg.max_positions)
@@ -526,15 +555,33 @@ class LlamaStack:
         saved = []
         if sel is not None and (sel.numel() % 8 != 0 or sel.numel() == 0):
             raise ValueError("LlamaStack.fwd: the number of selected rows must be a positive multiple of 8")
+        M = x.shape[0]
+        fold = (not train) and getattr(self, "folded", False) and _FOLD_RMSNORM and self._fold_ok(M)
+        part = rbuf = None
+        if fold:   # sums of squares of the first layer's input rows; every later layer's come out of the down projection's epilogue
+            part = ops.row_sumsq(x)
+            rbuf = torch.empty(M, dtype=F32, device=x.device)
         for li, l in enumerate(self.layers):
             last_sel = sel is not None and li == len(self.layers) - 1
-            h1, _, r1 = ops.norm_fwd(x, l["n1"], eps=cfg.rms_eps, rms=True, save_stats=train)
-            if _FUSE_ROPE_FWD and hd == 128:    # RoPE on the q | k heads in the projection's epilogue (ovla_gemm_args.rope_*)
-                qkv, s_qkv = l["qkv"].fwd(h1, rope=(cos, sin, S, 2 * D))
+            if fold:   # RMSNorm + RoPE + q|k|v in ONE launch: rstd from `part`, folded weight, rotation in the epilogue
+                qkv = ops.gemm(x, l["qkv_n"], rope=(cos, sin, S, 2 * D), rowscale=(part, cfg.rms_eps, rbuf))
+                s_qkv = r1 = None
             else:
-                qkv, s_qkv = l["qkv"].fwd(h1)
-                ops.rope_(qkv, S, 2 * H, hd, cos, sin)
+                h1, _, r1 = ops.norm_fwd(x, l["n1"], eps=cfg.rms_eps, rms=True, save_stats=train)
+                if _FUSE_ROPE_FWD and hd == 128:    # RoPE on the q | k heads in the projection's epilogue (ovla_gemm_args.rope_*)
+                    qkv, s_qkv = l["qkv"].fwd(h1, rope=(cos, sin, S, 2 * D))
+                else:
+                    qkv, s_qkv = l["qkv"].fwd(h1)
+                    ops.rope_(qkv, S, 2 * H, hd, cos, sin)
             o, lse = ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, S, H, hd, kv_len=kv_len, causal=causal)
+            if fold and not last_sel:
+                part2 = torch.empty((M, D // 64), dtype=F32, device=x.device)
+                x2 = ops.gemm(o, l["o"].W, residual=x, rowsq_out=part2)
+                gu = ops.gemm(x2, l["gu_n"], rowscale=(part2, cfg.rms_eps, rbuf))
+                hm = ops.swiglu_fwd(gu)
+                part = torch.empty((M, D // 64), dtype=F32, device=x.device)
+                x = ops.gemm(hm, l["down"].W, residual=x2, rowsq_out=part)
+                continue
             if last_sel:
                 x2, s_o = l["o"].fwd(ops.gather_rows(o, sel, D), residual=ops.gather_rows(x, sel, D))
             else:
@@ -784,6 +831,8 @@ class VLAEngine:
             self.head = build_component(ActionHead, device, get, "action_head.noise_predictor.mlp_resnet." if head == "diffusion" else "action_head.model.",
                                         cfg=cfg)
         self.refresh_derived()
+        if _FOLD_RMSNORM and not any(l.has_lora for l in self.llm.linears()):
+            self.llm.fold_norms()       # an adapter-free decoder (merged checkpoint): inference-only model, fold the RMSNorms (LlamaStack.fold_norms)
 
     @property
     def stores(self):
@@ -819,6 +868,8 @@ class VLAEngine:
             if isinstance(lin, LoraLinear):
                 lin.merge()
         self.lora_merged = True
+        if _FOLD_RMSNORM:
+            self.llm.fold_norms()       # adapter-free decoder: RMSNorm + RoPE + q|k|v (and RMSNorm + gate|up) become one launch each at inference
 
     def merged_state_dict(self) -> Dict[str, torch.Tensor]:
         """Base VLM weights under the reference's HF key layout (un-fused q/k/v, gate/up), after merge_lora(): what

@@ -73,7 +73,7 @@ def check_device(index: int = 0) -> None:
 
 # ----------------------------------------------------------------------------------------------------------------------
 def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=None, c_pre=None, a2=None, b2=None,
-         k2_group_n=0, film=None, split_k=1, tile=0, alpha=1.0, a_group_n=0, dact=None, rope=None):
+         k2_group_n=0, film=None, split_k=1, tile=0, alpha=1.0, a_group_n=0, dact=None, rope=None, rowsq_out=None, rowscale=None):
     """out[M,N] = epilogue(a[M,K] @ b[N,K]^T (+ a2[M,G*K2] @ b2[N,K2]^T)); all bf16 2-D, last dim contiguous."""
     _chk(a, name="a"); _chk(b, name="b")
     M, K = a.shape
@@ -119,6 +119,13 @@ def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=Non
         cos, sin, rS, rcols = rope
         assert cos.shape[1] == 64 and cos.shape[0] >= rS and cos.is_contiguous() and sin.is_contiguous()
         g.rope_cos, g.rope_sin, g.rope_S, g.rope_cols = cos.data_ptr(), sin.data_ptr(), rS, rcols
+    if rowsq_out is not None:   # RMSNorm fold, producer side: fp32 [M, N / 64] sums of squares of the output's 64-column groups
+        assert rowsq_out.dtype == torch.float32 and rowsq_out.shape == (M, N // 64) and rowsq_out.is_contiguous()
+        g.rowsq_out = rowsq_out.data_ptr()
+    if rowscale is not None:    # consumer side: (parts fp32 [M, K / 64], eps, rstd scratch fp32 [M]): C = epilogue(rstd[m] * alpha * acc)
+        parts, eps, rbuf = rowscale
+        assert parts.dtype == torch.float32 and parts.shape == (M, K // 64) and parts.is_contiguous() and rbuf.dtype == torch.float32 and rbuf.numel() >= M
+        g.rowscale_part, g.rowscale_slots, g.rowscale_eps, g.rowscale_r = parts.data_ptr(), K // 64, eps, rbuf.data_ptr()
     g.M, g.N, g.K, g.act, g.split_k, g.tile, g.alpha, g.a_group_n = M, N, K, act, split_k, tile, alpha, a_group_n
     ws = _workspace(a.device, max(4 * split_k * M * N if split_k > 1 else 0, _WS_BYTES))
     g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
@@ -189,6 +196,27 @@ def gemm_tn_grouped(problems):
     e0 = _prof_begin()
     _lib.check(_lib.lib().ovla_gemm_tn_grouped(arr, n, _stream()), "ovla_gemm_tn_grouped")
     _prof_end(e0, "gemm_tn", flops)
+
+
+def row_sumsq(x, out=None):
+    """out[m, j] = sum of squares of x[m, 64 j : 64 j + 64] (fp32 [rows, dim / 64]): the first decoder layer's RMSNorm-fold input."""
+    _chk(x, name="x")
+    rows, dim = x.shape
+    assert x.stride(1) == 1 and dim % 64 == 0
+    if out is None:
+        out = torch.empty((rows, dim // 64), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().ovla_row_sumsq(x.data_ptr(), x.stride(0), out.data_ptr(), rows, dim, _stream()), "ovla_row_sumsq")
+    return out
+
+
+def gemm_plan(M, N, K, K2=0, k2_group_n=0, workspace_bytes=_WS_BYTES):
+    """The schedule `tile = 0` would pick (ovla_gemm_plan, host only): (tile id, full tiles, remainder tiles, remainder splits, estimated seconds)."""
+    import ctypes
+
+    t, f, r, sp, est = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
+    _lib.check(_lib.lib().ovla_gemm_plan(M, N, K, K2, k2_group_n, ctypes.c_int64(workspace_bytes), ctypes.byref(t), ctypes.byref(f), ctypes.byref(r),
+                                         ctypes.byref(sp), ctypes.byref(est)), "ovla_gemm_plan")
+    return t.value, f.value, r.value, sp.value, est.value
 
 
 def lora_bwd(dy, Bt, t, dB_grad, *, gn, G, scale, dt=None):

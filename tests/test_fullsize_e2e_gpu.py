@@ -379,3 +379,50 @@ def test_conditioned_gradients_absolute(cond, dev):
     assert set(rep) == set(GRAD_ABS)
     for f, r in rep.items():
         assert r["median_hip"] <= GRAD_ABS[f][0] and r["max_hip"] <= GRAD_ABS[f][1], f"{f}: median {r['median_hip']:.4f} max {r['max_hip']:.4f} vs bounds {GRAD_ABS[f]}"
+
+
+def test_folded_rmsnorm_inference_parity(cond, dev):
+    """`north_star`'s "fused RMSNorm + RoPE + QKV" on the batch-1 inference path (LlamaStack.fold_norms: norm weight folded into the frozen weight,
+    row sums of squares out of the producing GEMM's epilogue, rstd applied in the consuming GEMM's epilogue ahead of the rotation): configs[1] at full
+    size on an adapter-free engine, against the fp32 oracle AND against the same engine with its RMSNorm launches.  The fold moves two bf16 rounding
+    points per norm (x * rstd, w * (.)) into one (the folded weight): it is another bf16 evaluation of the same function, so its distance to fp32 must
+    stay inside the SAME absolute bounds as the unfolded path's (ABS above), and the two paths differ from each other like two independent bf16
+    evaluations do (about sqrt(2) x their distance to fp32).  The arithmetic itself is checked tightly at kernel level (test_gemm_rmsnorm_fold)."""
+    load = importlib.import_module
+    engine_mod, weights_mod, ops = load("openvla-oft_amd.engine"), load("openvla-oft_amd.weights"), load("openvla-oft_amd.ops")
+    cfg, b8 = cond["cfg"], cond["batch8"]
+    sd = {k: v for k, v in cond["sd"].items() if ".lora_" not in k}
+    get, has = weights_mod.make_getter(sd, dev)
+    eng = engine_mod.VLAEngine(cfg, get, dev, lora=False, use_proprio=True, head="l1", has=has)
+    assert getattr(eng.llm, "folded", False), "an adapter-free decoder folds its RMSNorms at construction"
+    b = {k: v[:1] for k, v in b8.items()}
+    M = 1 + 2 * cfg.dino.n_patches + 1 + b["input_ids"].shape[1] - 1
+    assert eng.llm._fold_ok(M), f"the four decoder projections at M = {M} must resolve to the 128x128 GEMM configuration"
+    st32 = sh.oracle_stages(sh.oracle_config(cfg), sd, b, dev, "fp32", lm_head=False)
+    ah32, pred32 = st32["action_hidden"].float().reshape(-1, cfg.llm_dim), st32["pred"].float().reshape(-1, cfg.action_dim)
+    del st32
+
+    def run():
+        out = eng.forward(b["input_ids"], b["attention_mask"], b["pixel_values"].to(dev, BF), b["labels"], proprio=b["proprio"].to(dev, BF), train=False, sel="actions")
+        ah, _ = eng.action_hidden(out)
+        pred = eng.head.fwd(ah)[0]
+        torch.cuda.synchronize()
+        return ah.float().clone(), pred.float().clone()
+
+    ah_f, pred_f = run()
+    ah_f2, pred_f2 = run()
+    assert torch.equal(ah_f, ah_f2) and torch.equal(pred_f, pred_f2), "the folded path is bit-reproducible"
+    eng.llm.folded = False
+    ah_u, pred_u = run()
+    eng.llm.folded = True
+    rec = {"folded_vs_fp32": {"action_hidden_rel2": sh.rel2(ah_f, ah32), "pred_rel2": sh.rel2(pred_f, pred32), "pred_linf": (pred_f - pred32).abs().max().item()},
+           "unfolded_vs_fp32": {"action_hidden_rel2": sh.rel2(ah_u, ah32), "pred_rel2": sh.rel2(pred_u, pred32), "pred_linf": (pred_u - pred32).abs().max().item()},
+           "folded_vs_unfolded": {"action_hidden_rel2": sh.rel2(ah_f, ah_u), "pred_rel2": sh.rel2(pred_f, pred_u), "pred_linf": (pred_f - pred_u).abs().max().item()}}
+    print("\n" + json.dumps(rec))
+    _dump("fold_vs_unfolded.json", rec)
+    f = rec["folded_vs_fp32"]
+    assert f["action_hidden_rel2"] <= ABS["action_hidden_rel2"] and f["pred_rel2"] <= ABS["pred_rel2"] and f["pred_linf"] <= ABS["pred_linf_fp32"]
+    assert rec["folded_vs_unfolded"]["action_hidden_rel2"] <= 1.6 * ABS["action_hidden_rel2"]
+    del eng
+    gc.collect()
+    torch.cuda.empty_cache()

@@ -589,11 +589,11 @@ def test_attn_bwd_fused_inverse_rope(ops, dev, hd, S, causal):
 
 
 @pytest.mark.parametrize("M,S,tile", [(4864, 608, 0), (4864, 608, 116), (4864, 608, 117), (4864, 608, 17), (512, 128, 17), (608, 608, 0), (608, 608, 17),
-                                      (1216, 304, 16), (700, 100, 1), (520, 130, 2)])
+                                      (1216, 304, 16), (700, 100, 1), (520, 130, 2), (608, 608, 1), (608, 608, 101), (1000, 250, 101), (4864, 608, 101)])
 def test_gemm_rope_epilogue(ops, dev, M, S, tile):
     """RoPE in the q|k|v projection's epilogue (fused in the 256x256 configs: 2x4 waves = the default layout, in its unrolled read-back with
-    the partner-column wave map, and 4x2 waves; both incl. the hybrid-remainder reduce; other schedules and non-multiple-of-256 M append one
-    ovla_rope launch) == plain GEMM followed by the separate RoPE pass, bit for bit.  2 q | 2 k | 2 v heads of 128: q | k rotated, v untouched."""
+    the partner-column wave map, and 4x2 waves; since round 3 also in the 128x128 config -- one head per column tile, any M: the batch-1 chunk's
+    M = 608; all incl. the hybrid-remainder reduce; other schedules append one ovla_rope launch) == plain GEMM followed by the separate RoPE pass, bit for bit.  2 q | 2 k | 2 v heads of 128: q | k rotated, v untouched."""
     torch.manual_seed(M + tile)
     hd, K = 128, 512
     N = 3 * 2 * hd                      # 2 q heads | 2 k heads | 2 v heads
@@ -723,3 +723,42 @@ def test_lora_bwd_one_pass(ops, dev, M, gn, G):
     dt_old = ops.gemm(dy, Bt, alpha=s, a_group_n=r if G > 1 else 0) if (G == 1 or gn % 128 == 0) else None
     if dt_old is not None:
         assert (dt.float() - dt_old.float()).abs().max().item() <= 2.0 ** -7 * dt_old.float().abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K,tile,rope", [(608, 1024, 512, 1, False), (608, 768, 1024, 1, True), (1000, 1024, 512, 101, False), (300, 640, 512, 101, True)])
+def test_gemm_rmsnorm_fold(ops, dev, M, N, K, tile, rope):
+    """RMSNorm folded around the 128x128 GEMM (ovla_gemm_args.rowsq_out / rowscale_part; LlamaStack.fold_norms): the producer's epilogue writes the
+    sums of squares of its bf16 output's 64-column groups; the consumer scales its accumulator by rstd[m] = rsqrt(sum / K + eps) before the
+    (RoPE) epilogue -- against torch fp32 on the same bf16 operands, interior and edge row tiles, in-kernel epilogue and hybrid-remainder reduce,
+    and bit-reproducible between runs (slots are summed in a fixed order)."""
+    torch.manual_seed(M + N + tile)
+    eps = 1e-5
+    # producer: x = a . b^T + residual, with per-64-column sums of squares of the stored x
+    a, b, res = rnd(M, 512, dev=dev, scale=0.5), rnd(K, 512, dev=dev, scale=0.1), rnd(M, K, dev=dev)
+    part = torch.full((M, K // 64), float("nan"), device=dev)
+    x = ops.gemm(a, b, residual=res, tile=tile, rowsq_out=part)
+    ref_x = ops.gemm(a, b, residual=res, tile=tile)
+    assert torch.equal(x, ref_x), "the sums of squares ride along: the output itself is unchanged"
+    ref_part = x.float().view(M, K // 64, 64).pow(2).sum(-1)
+    assert torch.isfinite(part).all() and ((part - ref_part).abs() <= 1e-5 * ref_part.abs().max()).all()
+    assert torch.allclose(ops.row_sumsq(x), ref_part, rtol=1e-5, atol=1e-5 * ref_part.abs().max().item())
+    # consumer: y = rope(rstd[m] * (x . Wn^T))
+    wn = rnd(N, K, dev=dev, scale=0.05)
+    rbuf = torch.empty(M, device=dev)
+    S = 152 if rope else 0
+    kw = {}
+    if rope:
+        cos, sin = ops.rope_table(S, 128, 10000.0, dev)
+        kw["rope"] = (cos, sin, S, N - 256)          # leading heads rotated, the last two head widths are "v"
+    y = ops.gemm(x, wn, tile=tile, rowscale=(part, eps, rbuf), **kw)
+    rstd = torch.rsqrt(part.sum(-1) / K + eps)
+    assert torch.allclose(rbuf, rstd, rtol=2e-6, atol=0)
+    ref = ((x.float() @ wn.float().T) * rstd[:, None]).to(BF)
+    if rope:
+        ops.rope_(ref, S, (N - 256) // 128, 128, cos, sin)
+    close(y, ref, tol=1.2e-2, what="folded RMSNorm GEMM")
+    y2 = ops.gemm(x, wn, tile=tile, rowscale=(part, eps, torch.empty(M, device=dev)), **kw)
+    assert torch.equal(y, y2)
+    # any other tile configuration must refuse the fold instead of ignoring it
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, wn, tile=17, rowscale=(part, eps, rbuf))
