@@ -303,26 +303,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   constexpr size_t NF_KB = (size_t)2 * TILE_ELEMS * sizeof(bf16_bits), NF_EB = (size_t)NW * (MT < 2 ? MT : 2) * 16 * (WTN + 4) * sizeof(float);
   float* s_rstd = reinterpret_cast<float*>(smem_raw + (NF_KB > NF_EB ? NF_KB : NF_EB));
   bool rowscale = false;
-  if constexpr (NORMFOLD) {
-    rowscale = p.rowscale_part != nullptr;
-    if (rowscale) {
-      const int row = tid >> 1, half = tid & 1, m = m0 + row;
-      float ssum = 0.f;
-      if (m < p.M) {
-        const int per = p.rowscale_slots >> 1;             // slots this lane adds, in slot order (rowscale_slots % 8 == 0: host-checked)
-        const float* src = p.rowscale_part + (int64_t)m * p.rowscale_slots + half * per;
-        for (int j = 0; j < per; j += 4) {
-          const f32x4 q = *reinterpret_cast<const f32x4*>(src + j);
-          ssum += q[0]; ssum += q[1]; ssum += q[2]; ssum += q[3];
-        }
-      }
-      ssum += __shfl_xor(ssum, 1, 64);
-      const float r = m < p.M ? rsqrtf(ssum / (float)(p.rowscale_slots * 64) + p.rowscale_eps) : 0.f;
-      s_rstd[row] = r;
-      if (half == 0 && m < p.M && tn == 0 && split == 0 && p.rowscale_r) p.rowscale_r[m] = r;   // for the hybrid-remainder reduce kernel
-    }
-  }
-
   uint32_t offA[BM / 8 / NW], offB[BN / 8 / NW];
   stage_offsets<BM, NW>(offA, p.lda, OVLA_DBG(4) ? 0 : m0, p.M - 1, wave, lane);
   stage_offsets<BN, NW>(offB, p.ldb, OVLA_DBG(4) ? 0 : n0, p.N - 1, wave, lane);
@@ -454,6 +434,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   };
 
   if (t_begin < t_end) stage(t_begin, 0);
+  // (the fold's prologue loads are issued AFTER the first K tile's LDS-DMA, so the two latencies overlap: issued first, their wait delayed the DMA by a
+  // whole memory round trip -- measured: the removed norm launches' time came back inside the GEMMs)
+  if constexpr (NORMFOLD) {
+    rowscale = p.rowscale_part != nullptr;
+    if (rowscale) {
+      const int row = tid >> 1, half = tid & 1, m = m0 + row;
+      float ssum = 0.f;
+      if (m < p.M) {
+        const int per = p.rowscale_slots >> 1;             // slots this lane adds, in slot order (rowscale_slots % 8 == 0: host-checked)
+        const float* src = p.rowscale_part + (int64_t)m * p.rowscale_slots + half * per;
+        for (int j0 = 0; j0 < per; j0 += 32) {   // batches of eight independent 16-byte loads (all in flight together), added in slot order
+          f32x4 q[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) q[u] = (j0 + 4 * u < per) ? *reinterpret_cast<const f32x4*>(src + j0 + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { ssum += q[u][0]; ssum += q[u][1]; ssum += q[u][2]; ssum += q[u][3]; }
+        }
+      }
+      ssum += __shfl_xor(ssum, 1, 64);
+      const float r = m < p.M ? rsqrtf(ssum / (float)(p.rowscale_slots * 64) + p.rowscale_eps) : 0.f;
+      s_rstd[row] = r;
+      if (half == 0 && m < p.M && tn == 0 && split == 0 && p.rowscale_r) p.rowscale_r[m] = r;   // for the hybrid-remainder reduce kernel
+    }
+  }
+
   int t = t_begin;
   {
     const int lim = t_end < t_fast ? t_end : t_fast;   // spread loop: tile t+1 exists and is a fast-address tile
