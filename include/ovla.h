@@ -103,6 +103,10 @@ typedef struct {
    * Supported on the 128x128 tile only (tile 1 / 101, what the batch-1 shapes M <= ~1k resolve to); any other schedule is an error. */
   float* rowsq_out;
   const float* rowscale_part; int32_t rowscale_slots; float rowscale_eps; float* rowscale_r;
+  /* In-launch reduce of the hybrid schedule's K-split remainder tiles: device array of n_hybrid_counters uint32, ALL ZERO on entry (the kernel
+   * leaves it all zero).  The last of a tile's K-part workgroups to arrive sums the slabs in slab order and runs the epilogue, so no separate
+   * reduce launch is needed; same bits either way.  NULL / too few counters: a gemm_hybrid_reduce launch follows as before. */
+  uint32_t* hybrid_counters; int32_t n_hybrid_counters;
   void* workspace;               /* fp32 scratch: [split_k, M, N] when split_k > 1; also enables the auto schedules */
   int64_t workspace_bytes;       /* (hybrid remainder split, skinny-N split-K) when tile == 0; may be NULL/0 */
 } ovla_gemm_args;

@@ -57,6 +57,8 @@ struct GemmParams {
   // RMSNorm fold (ovla.h): producer writes per-row sums of squares of its output's 64-column groups; consumer scales the accumulator by rstd[m]
   float* rowsq_out;
   const float* rowscale_part; int rowscale_slots; float rowscale_eps; float* rowscale_r;
+  int hyb_cnt_n;
+  unsigned* hyb_cnt;   // per-remainder-tile arrival counters (all zero between launches) for the in-launch reduce; nullptr: separate reduce kernel
 };
 
 // sum of squares of 4 bf16-rounded outputs, reduced over the 16 lanes that hold one row's 64-column group (lanes aligned to 16)
@@ -228,6 +230,9 @@ OVLA_DEV void rope_store(const GemmParams& p, int m, int n, f32x4 v, f32x4 vp) {
   }
   *reinterpret_cast<bf16x4_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
 }
+
+template <int BM, int BN>
+OVLA_DEV void hybrid_reduce_quads(const GemmParams& p, int rt, int q0, int qstride);
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams p) {
@@ -485,6 +490,30 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         *reinterpret_cast<f32x4*>(slab + (wm * WTM + i * 16 + (lane & 15)) * BN + bcol[j] + 4 * (lane >> 4)) = acc[i][j];
+    if (p.hyb_cnt == nullptr) return;          // the separate gemm_hybrid_reduce_kernel launch does the rest
+    // In-launch reduce: the LAST of a tile's rem_splits units to arrive adds the slabs (its own included, from memory, in slab order: the same
+    // bits as the reduce kernel) and runs the epilogue.  Arrival = agent-scope release of the workgroup's slab stores + one relaxed atomic on the
+    // tile's counter; no unit ever waits for another (no co-residency requirement, no deadlock); the last arriver re-zeroes the counter, so the
+    // caller's counter array stays all-zero between launches.
+    // (the flag lives in the first word of the K-tile buffers, free after the barrier below: a second __shared__ object would move the dynamic LDS
+    // base and push the 256x256 config's LDS-DMA destinations across the 128 KiB line)
+    volatile int* s_last_p = reinterpret_cast<volatile int*>(smem_raw);
+    __syncthreads();                           // every wave's slab stores have completed (the barrier's vmcnt(0)) and nobody reads the K tiles any more ...
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // ... and are written back where other XCDs' CUs will read them
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int rt0 = rem_unit / p.rem_splits;
+      const unsigned old = __hip_atomic_fetch_add(p.hyb_cnt + rt0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == (unsigned)(p.rem_splits - 1);
+      if (last) {
+        __hip_atomic_store(p.hyb_cnt + rt0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      *s_last_p = last;
+    }
+    __syncthreads();
+    if (!*s_last_p) return;
+    hybrid_reduce_quads<BM, BN>(p, rem_unit / p.rem_splits, tid, 64 * NW);
     return;
   }
   if (p.split_k > 1) {  // raw fp32 partials; the reduce kernel applies the epilogue
@@ -1015,10 +1044,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParam
   }
 }
 
-// sums the rem_splits partial slabs of every remainder tile and applies the epilogue
+// Sums the rem_splits partial slabs of remainder tile `rt` IN SLAB ORDER and applies the epilogue, for the quads q = q0, q0 + qstride, ...:
+// the body of gemm_hybrid_reduce_kernel and of the GEMM kernel's in-launch reduce (the last unit of a tile to arrive), so both give the same bits.
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_hybrid_reduce_kernel(const GemmParams p) {
-  const int rt = blockIdx.y;
+OVLA_DEV void hybrid_reduce_quads(const GemmParams& p, int rt, int q0, int qstride) {
   const int t_mn = p.full_tiles + rt;
   constexpr int GROUP = 8;
   const int group_sz = GROUP * p.tiles_n;
@@ -1028,7 +1057,7 @@ __global__ __launch_bounds__(256) void gemm_hybrid_reduce_kernel(const GemmParam
   const int in_group = t_mn - gid * group_sz;
   const int m0 = (first_m + in_group % gm) * BM, n0 = (in_group / gm) * BN;
   const float* slab0 = p.ws + (int64_t)rt * p.rem_splits * (BM * BN);
-  for (int q = blockIdx.x * 256 + threadIdx.x; q < BM * BN / 4; q += gridDim.x * 256) {
+  for (int q = q0; q < BM * BN / 4; q += qstride) {
     const int lm = q / (BN / 4), ln = (q % (BN / 4)) * 4;
     const int m = m0 + lm, n = n0 + ln;
     if (m >= p.M || n >= p.N) continue;
@@ -1047,6 +1076,11 @@ __global__ __launch_bounds__(256) void gemm_hybrid_reduce_kernel(const GemmParam
       if (((ln >> 2) & 15) == 0) p.rowsq_out[(int64_t)m * (p.N >> 6) + (n >> 6)] = sq;
     }
   }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_hybrid_reduce_kernel(const GemmParams p) {
+  hybrid_reduce_quads<BM, BN>(p, blockIdx.y, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 static int g_num_cus = 0;
@@ -1155,12 +1189,15 @@ int launch_cfg(GemmParams& p, hipStream_t stream, int64_t ws_bytes = 0, bool hyb
     const HybridPlan pl = plan_hybrid(p.M, p.N, p.T1 + p.T2, tile_cfg(BM, BN), ws_bytes / 4);
     p.full_tiles = pl.full_tiles; p.rem_tiles = pl.rem_tiles; p.rem_splits = pl.rem_splits;
   }
+  if (p.rem_tiles == 0 || p.rem_tiles > p.hyb_cnt_n) p.hyb_cnt = nullptr;    // no remainder, or more remainder tiles than counters: separate reduce launch
   const unsigned nblk = p.rem_tiles > 0 ? (unsigned)(p.full_tiles + p.rem_tiles * p.rem_splits) : (unsigned)(tiles * splits);
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(64 * WM * WN), lds, stream, p);
   OVLA_CHECK_LAUNCH("ovla_gemm_bf16");
-  if (p.rem_tiles > 0) {
+  if (p.rem_tiles > 0 && p.hyb_cnt == nullptr) {
     hipLaunchKernelGGL((gemm_hybrid_reduce_kernel<BM, BN>), dim3(BM * BN / 4 / 256 / 4, p.rem_tiles), dim3(256), 0, stream, p);
     OVLA_CHECK_LAUNCH("ovla_gemm_bf16(hybrid reduce)");
+  } else if (p.rem_tiles > 0) {
+    // reduced inside the GEMM launch by each tile's last-arriving unit
   } else if (splits > 1) {
     const int64_t quads = (int64_t)p.M * (p.N / 4);
     int blocks = cdiv(quads, 256);
@@ -1278,6 +1315,7 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   p.alpha = a->alpha == 0.f ? 1.f : a->alpha;
   p.dact_src = (const bf16_bits*)a->dact_src; p.ld_dact = a->ld_dact; p.dact_mode = a->dact_src ? a->dact_mode : 0; p.dact_act = a->dact_act;
   p.rope_cos = nullptr; p.rope_sin = nullptr; p.rope_S = a->rope_S; p.rope_cols = a->rope_cols;   // enabled below for the config that fuses it
+  p.hyb_cnt = (unsigned*)a->hybrid_counters; p.hyb_cnt_n = a->hybrid_counters ? a->n_hybrid_counters : 0;
   p.rowsq_out = a->rowsq_out; p.rowscale_part = a->rowscale_part; p.rowscale_slots = a->rowscale_slots; p.rowscale_eps = a->rowscale_eps; p.rowscale_r = a->rowscale_r;
   if (a->rowsq_out) OVLA_REQUIRE((a->N % 64) == 0 && a->split_k <= 1 && !a->dact_src && !a->film_gamma && (((uintptr_t)a->rowsq_out) & 3) == 0,
                                  "ovla_gemm_bf16: rowsq_out needs N %% 64 == 0, no split_k and a forward epilogue");

@@ -37,6 +37,26 @@ def _workspace(device, nbytes):
     return ws
 
 
+# Arrival counters of the in-launch hybrid reduce (ovla_gemm_args.hybrid_counters): one zeroed array per (device, stream), which the kernels
+# keep all-zero.  OPT-IN (OVLA_HYBRID_INLAUNCH=1): bit-identical to the separate gemm_hybrid_reduce launch but measured SLOWER on every hybrid
+# shape (tools/hybrid_ab.py, profiles/r03_hybrid_inlaunch_ab.txt: 4864 x 4096 x 4096 214 vs 160 us, 608 x 4096 x 4096 67.5 vs 38.5 us) -- the
+# agent-scope release each K-part workgroup needs before it signals writes back its XCD's whole L2 (the other tiles' output lines included),
+# which costs far more than the 15 us launch it removes.
+import os as _os
+
+_HYB_INLAUNCH = _os.environ.get("OVLA_HYBRID_INLAUNCH", "0") == "1"
+_HYB_N = 4096
+_hyb_cache = {}
+
+
+def _hybrid_counters(device):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    c = _hyb_cache.get(key)
+    if c is None:
+        c = _hyb_cache[key] = torch.zeros(_HYB_N, dtype=torch.int32, device=device)
+    return c
+
+
 def _prof_begin():
     if PROFILE is None:
         return None
@@ -129,6 +149,8 @@ def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=Non
     g.M, g.N, g.K, g.act, g.split_k, g.tile, g.alpha, g.a_group_n = M, N, K, act, split_k, tile, alpha, a_group_n
     ws = _workspace(a.device, max(4 * split_k * M * N if split_k > 1 else 0, _WS_BYTES))
     g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if _HYB_INLAUNCH:
+        g.hybrid_counters, g.n_hybrid_counters = _hybrid_counters(a.device).data_ptr(), _HYB_N
     e0 = _prof_begin()
     _lib.call("ovla_gemm_bf16", g, _stream())
     if e0 is not None:

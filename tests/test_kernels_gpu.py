@@ -762,3 +762,27 @@ def test_gemm_rmsnorm_fold(ops, dev, M, N, K, tile, rope):
     # any other tile configuration must refuse the fold instead of ignoring it
     with pytest.raises(RuntimeError):
         ops.gemm(x, wn, tile=17, rowscale=(part, eps, rbuf))
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(4864, 4096, 1024, 117), (608, 4096, 2048, 101), (608, 1024, 4096, 102), (1000, 768, 512, 101), (4864, 1024, 512, 0)])
+def test_hybrid_reduce_in_launch_equals_the_reduce_kernel(ops, dev, M, N, K, tile):
+    """The hybrid schedule's K-split remainder tiles reduced INSIDE the GEMM launch (the last-arriving K part of a tile sums the slabs in slab
+    order and runs the epilogue; ovla_gemm_args.hybrid_counters) against the separate gemm_hybrid_reduce launch: bit-identical outputs incl. bias /
+    residual epilogues and the LoRA K-extension, repeated launches (the counters must be all zero again after every launch)."""
+    torch.manual_seed(M + N)
+    a, b = rnd(M, K, dev=dev, scale=0.5), rnd(N, K, dev=dev, scale=0.1)
+    t, lb, res, bias = rnd(M, 32, dev=dev), rnd(N, 32, dev=dev, scale=0.2), rnd(M, N, dev=dev), rnd(N, dev=dev)
+    kw = dict(a2=t, b2=lb, residual=res, bias=bias, tile=tile)
+    prev = ops._HYB_INLAUNCH
+    try:
+        ops._HYB_INLAUNCH = False
+        ref = ops.gemm(a, b, **kw)
+        ops._HYB_INLAUNCH = True
+        outs = [ops.gemm(a, b, **kw) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert int(ops._hybrid_counters(dev).abs().sum().item()) == 0, "arrival counters must be zero between launches"
+    finally:
+        ops._HYB_INLAUNCH = prev
+    for o in outs:
+        assert torch.equal(o, ref), f"{(o != ref).sum().item()} of {ref.numel()} differ"
+    close(ref, a.float() @ b.float().T + t.float() @ lb.float().T + bias.float() + res.float(), tol=2e-2, what="hybrid GEMM vs torch")
