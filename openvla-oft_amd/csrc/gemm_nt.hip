@@ -887,7 +887,7 @@ OVLA_DEV void wait_vmcnt() {
   else static_assert(N == 0, "add the vmcnt literal");
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_pipe_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -962,6 +962,87 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_pipe_kernel(const GemmPa
   for (int s = 0; s < D; ++s)
     if (t_begin + s < t_end) stage(t_begin + s);
 
+  if constexpr (MODE == 1) {
+    // Round-3 variant of the ring: the BK = 64 loop's structure on BK = 32 stages.  (1) The LAST m-tile row of every stage is deferred across
+    // the barrier: its fragments stay in registers (a_def, the previous stage's B fragments) and its NT MFMAs issue right after the next
+    // stage's first fragment reads, so the matrix pipe has work while those reads are in flight instead of draining at every barrier -- with a
+    // barrier per 32 K elements that drain was the ring's 17 %.  (2) The refill of the freed slot is not one burst after the barrier: its G
+    // LDS-DMA pieces go out one per row slot.  Stages alternate between two B-fragment register sets (no copies).
+    static_assert(MT >= 2 && G <= MT - 1, "tuned ring: one DMA piece per row slot");
+    constexpr int PA = BM / 16 / NW;
+    bf16x8_bits bfr[2][NT];
+    bf16x8_bits a_def = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bfr[1][j] = a_def;
+    const int chunk = lane >> 4;
+    const int arow = wm * WTM + (lane & 15), brow = wn * WTN + (lane & 15);
+    auto body = [&](const int t, auto par_tag) {
+      constexpr int PAR = decltype(par_tag)::value;
+      const int newer = (t_end - 1 - t) < (D - 1) ? (t_end - 1 - t) : (D - 1);
+      if (newer >= 3) wait_vmcnt<3 * G>();
+      else if (newer == 2) wait_vmcnt<2 * G>();
+      else if (newer == 1) wait_vmcnt<G>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      const bf16_bits* sA = smem + ((t - t_begin) % STAGES) * STAGE_ELEMS;
+      const bf16_bits* sB = sA + BM * PK;
+      const int tn = t + D;                                  // the stage that refills the slot stage t - 1 used
+      const bool refill = tn < t_end, fast = tn < t_fast;
+      bf16_bits* nA = smem + ((tn - t_begin) % STAGES) * STAGE_ELEMS;
+      bf16_bits* nB = nA + BM * PK;
+      const char* gA = reinterpret_cast<const char*>(p.A) + (int64_t)tn * (PK * 2);
+      const char* gB = reinterpret_cast<const char*>(p.B) + (int64_t)tn * (PK * 2);
+      if (refill && !fast) stage(tn);                        // K tail / LoRA K-extension stages: the simple burst
+      auto piece = [&](auto q_tag) {
+        constexpr int q = decltype(q_tag)::value;
+        if (refill && fast) {
+          if constexpr (q < PA)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + offA[q]),
+                                             (__attribute__((address_space(3))) void*)(nA + (wave * PA + q) * 16 * PK), 16, 0, 0);
+          else
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + offB[q - PA]),
+                                             (__attribute__((address_space(3))) void*)(nB + (wave * (G - PA) + (q - PA)) * 16 * PK), 16, 0, 0);
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bfr[PAR][j] = lds_frag32(sB, brow + j * 16, chunk);
+      bf16x8_bits a_cur = lds_frag32(sA, arow, chunk);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)      // deferred last row of the previous stage (zeros on the first pass)
+        acc[MT - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[PAR ^ 1][j], a_def, acc[MT - 1][j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+      static_for<MT - 1>([&](auto i_tag) {
+        constexpr int i = decltype(i_tag)::value;
+        const bf16x8_bits a_nxt = lds_frag32(sA, arow + (i + 1) * 16, chunk);
+        if constexpr (i < G) piece(std::integral_constant<int, i>{});
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[PAR][j], a_cur, acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if constexpr (i < G) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+        a_cur = a_nxt;
+      });
+      a_def = a_cur;
+      __builtin_amdgcn_s_setprio(0);
+    };
+    int t = t_begin;
+    for (; t + 1 < t_end; t += 2) {
+      body(t, std::integral_constant<int, 0>{});
+      body(t + 1, std::integral_constant<int, 1>{});
+    }
+    int last_par = 1;
+    if (t < t_end) { body(t, std::integral_constant<int, 0>{}); last_par = 0; }
+    // the last stage's deferred row
+    if (last_par == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[MT - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[0][j], a_def, acc[MT - 1][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[MT - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[1][j], a_def, acc[MT - 1][j], 0, 0, 0);
+    }
+  } else
   for (int t = t_begin; t < t_end; ++t) {
     // stage t has landed once at most (stages issued after it) x G of this wave's DMAs are still outstanding
     const int newer = (t_end - 1 - t) < (D - 1) ? (t_end - 1 - t) : (D - 1);
@@ -1208,7 +1289,7 @@ int launch_cfg(GemmParams& p, hipStream_t stream, int64_t ws_bytes = 0, bool hyb
   return OVLA_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, int MODE = 0>
 int launch_pipe(GemmParams& p, hipStream_t stream) {
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_n = cdiv(p.N, BN);
@@ -1222,7 +1303,7 @@ int launch_pipe(GemmParams& p, hipStream_t stream) {
   size_t lds = (size_t)STAGES * (BM + BN) * PK * sizeof(bf16_bits);
   const size_t epi = (size_t)WM * WN * 32 * (BN / WN + 4) * sizeof(float);
   if (epi > lds) lds = epi;
-  auto kern = gemm_nt_pipe_kernel<BM, BN, WM, WN, STAGES>;
+  auto kern = gemm_nt_pipe_kernel<BM, BN, WM, WN, STAGES, MODE>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1405,6 +1486,8 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     case 13: return launch_pipe<128, 256, 2, 4, 5>(p, stream);
     case 14: return launch_pipe<128, 128, 2, 2, 4>(p, stream);
     case 15: return launch_pipe<256, 256, 2, 4, 3>(p, stream);
+    case 20: return launch_pipe<256, 256, 2, 4, 4, 1>(p, stream);   // round-3 tuned ring (deferred row + spread refill), 4 and 3 stages
+    case 21: return launch_pipe<256, 256, 2, 4, 3, 1>(p, stream);
     case 16: return launch_cfg<256, 256, 4, 2>(p, stream, wsb, hybrid);   // 4x2 waves (64x128 wave tiles): 1-3 % behind 2x4; one head per wave slab (fused RoPE)
     case 116: return launch_cfg<256, 256, 4, 2>(p, stream, wsb, true);
     case 17: return launch_cfg<256, 256, 2, 4>(p, stream, wsb, hybrid);   // 2x4 waves (128x64 wave tiles)

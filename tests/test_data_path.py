@@ -388,3 +388,31 @@ def test_jpeg_roundtrip_kernel_is_bit_identical_to_libjpeg_turbo(dev):
     assert a.shape == (224, 224, 3) and a.dtype == np.uint8 and not np.array_equal(a, b)
     with pytest.raises(Exception, match="quality"):
         ops.jpeg_roundtrip(torch.from_numpy(frame)[None].to(dev), quality=0)
+
+
+@pytest.mark.parametrize("tag", ["libero", "nostop", "primary_only", "ur5e"])
+def test_g20_batch_transform_matches_the_reference_class(tag):
+    """The mirror's RLDSBatchTransform against the REFERENCE's own class executed in the build container (prismatic/vla/datasets/datasets.py:26-97 with its
+    PurePromptBuilder, base_prompter.py:28-73; tests/golden/make_golden_batch_transform.py, shared stand-in tokenizer tests/duck_tokenizer.py): input ids,
+    labels (IGNORE_INDEX masking arithmetic, predict_stop_token), which observation keys become wrist images, actions and proprio passthrough, the ur5e
+    key names -- and the oracle's restatement of the id / label layout (oracle/data_oracle.py: batch_transform_ids)."""
+    from tests.duck_tokenizer import DuckTokenizer, mirror_tokenizer
+
+    g = dict(np.load(Path(__file__).resolve().parent / "golden" / "g20_ref_batch_transform.npz", allow_pickle=False))
+    wrist, prop, stop = (bool(x) for x in g[f"{tag}.flags"])
+    name, lang = bytes(g[f"{tag}.dataset_name"]), bytes(g[f"{tag}.language"])
+    obs = {k[len(tag) + 5:]: v for k, v in g.items() if k.startswith(f"{tag}.obs.")}
+    frame = {"dataset_name": name, "action": g[f"{tag}.action"], "observation": obs, "task": {"language_instruction": lang}}
+    at = AT.ActionTokenizer(DuckTokenizer())
+    out = R.RLDSBatchTransform(at, mirror_tokenizer, use_wrist_image=wrist, use_proprio=prop, predict_stop_token=stop)(frame)
+    assert np.array_equal(out["input_ids"].numpy(), g[f"{tag}.input_ids"]) and np.array_equal(out["labels"].numpy(), g[f"{tag}.labels"])
+    assert np.array_equal(np.asarray(out["actions"]), g[f"{tag}.actions"])
+    assert np.array_equal(out["image"], g[f"{tag}.pixel_values"]), "primary frame (identity image transform on both sides)"
+    if wrist:
+        assert np.array_equal(np.concatenate(out["image_wrist"], 0), g[f"{tag}.pixel_values_wrist"])
+    if prop:
+        assert np.array_equal(np.asarray(out["proprio"]), g[f"{tag}.proprio"])
+    # the prompt the mirror builds is the reference prompt builder's, token for token (get_prompt() strips the trailing space; the mirror tokenises the stripped text)
+    assert mirror_tokenizer(R.build_prompt(lang.decode().lower()).rstrip()) == g[f"{tag}.prompt_ids"].tolist()
+    ids, labels = do.batch_transform_ids(mirror_tokenizer(R.build_prompt(lang.decode().lower()).rstrip()), at.token_ids(g[f"{tag}.action"].reshape(-1)), predict_stop_token=stop)
+    assert ids == g[f"{tag}.input_ids"].tolist() and labels == g[f"{tag}.labels"].tolist()

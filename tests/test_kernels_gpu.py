@@ -58,7 +58,7 @@ GEMM_SHAPES = [(128, 128, 64), (200, 136, 72), (1000, 512, 1024), (64, 256, 2048
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 10, 11, 12, 13, 14, 15, 16, 17, 20, 21])
 def test_gemm_plain(ops, dev, M, N, K, tile):
     torch.manual_seed(M * 7 + N * 3 + K + tile)
     a, b = rnd(M, K, dev=dev), rnd(N, K, dev=dev)
@@ -107,7 +107,7 @@ def test_gemm_film_epilogue(ops, dev):
     close(dy, (d3 * (1 + gamma.float()).to(BF).float()[:, None]).reshape(Bn * rows, N), what="film dx")
 
 
-@pytest.mark.parametrize("tile", [0, 10, 11, 14])
+@pytest.mark.parametrize("tile", [0, 10, 11, 14, 20, 21])
 @pytest.mark.parametrize("groups,K2", [(1, 32), (3, 32), (2, 64), (1, 16)])
 def test_gemm_lora_extension(ops, dev, groups, K2, tile):
     torch.manual_seed(groups * 10 + K2)
