@@ -498,3 +498,73 @@ def test_g19_diffusion_predict_action_loop_matches_reference(mode):
                                    num_diffusion_steps=int(g["diffusion.T"]))
     assert np.abs(ah.numpy() - g[f"{mode}.film.predict.p.diffusion.hidden"]).max() < 2e-4
     assert np.abs(act - g[f"{mode}.film.predict.p.diffusion.actions"]).max() < 2e-4
+
+
+# ======================================================================================================================
+# G21: the reference's OWN run_forward_pass (vla-scripts/finetune.py:280-451), executed (tests/golden/make_golden_run_forward_pass.py)
+# ======================================================================================================================
+def _g21_parts(g, mode, sd, diffusion=None):
+    """The oracle's pieces composed as the fixture's run composed the reference's: VLM in fp32 (a CPU model), action rows rounded to bf16
+    (finetune.py:389-394 `.to(torch.bfloat16)`), head in bf16 (finetune.py:910)."""
+    cfg = vo.tiny_config()
+    b = {k: torch.from_numpy(g[k]) for k in ("input_ids", "attention_mask", "labels", "pixel_values", "proprio", "actions")}
+    o32, o16 = vo.Oracle(cfg, sd, mode="fp32", mask_mode=mode), vo.Oracle(cfg, sd, mode="bf16", mask_mode=mode)
+    kw = {}
+    if diffusion is not None:
+        kw = dict(noisy_actions=diffusion["noisy"], timestep_emb=vo.sinusoidal_encoding(diffusion["timesteps"].float(), cfg.llm_dim)[:, None, :], use_film=True)
+    hidden, P = o32.multimodal_hidden(b["input_ids"], b["attention_mask"], b["pixel_values"], b["labels"], b["proprio"], **kw)
+    ids = b["labels"][:, 1:]
+    m = vo.current_action_mask(ids, cfg.action_dim) | vo.next_actions_mask(ids, cfg.action_dim)
+    ah = hidden[:, P:-1][m].reshape(b["input_ids"].shape[0], cfg.chunk * cfg.action_dim, -1)
+    return cfg, b, o32, o16, o16.R(ah), P
+
+
+@pytest.mark.parametrize("mode", ["bidirectional", "causal"])
+def test_g21_run_forward_pass_l1_and_discrete_match_reference(mode):
+    """L1-regression objective: loss and the current / next action L1 metrics; discrete objective: the next-token cross entropy, the predicted ids
+    `logits[:, num_patches:-1].argmax`, both token accuracies and both decoded-L1 metrics -- against the reference function's own numbers."""
+    g = load("g21_ref_run_forward_pass.npz")
+    sd = _ref_sd(g)
+    cfg, b, o32, o16, ah16, P = _g21_parts(g, mode, sd)
+    with torch.no_grad():
+        pred = o16.l1_head(ah16)
+        gt = o16.R(b["actions"])
+        l1 = lambda a, c: float(o16.R(o16.R((a - c).abs()).mean()))  # noqa: E731  (torch.nn.L1Loss on bf16 tensors)
+        ulp = 2.0 ** -8
+        assert abs(l1(gt, pred) - float(g[f"{mode}.l1.loss"])) <= 2 * ulp
+        assert abs(l1(gt[:, 0], pred[:, 0]) - float(g[f"{mode}.l1.curr_action_l1_loss"])) <= 3 * ulp
+        assert abs(l1(gt[:, 1:], pred[:, 1:]) - float(g[f"{mode}.l1.next_actions_l1_loss"])) <= 2 * ulp
+        assert float(g[f"{mode}.l1.loss_value"]) == float(g[f"{mode}.l1.loss"])
+        # discrete objective on the lm_head with boosted action rows
+        sd_d = dict(sd)
+        lm = sd["language_model.lm_head.weight"].clone()
+        lm[31744:32000] *= float(g["lm_action_gain"])
+        sd_d["language_model.lm_head.weight"] = lm
+        loss, pred_ids = vo.Oracle(cfg, sd_d, mode="fp32", mask_mode=mode).train_forward_discrete(b)
+    assert abs(loss.item() - float(g[f"{mode}.discrete.loss"])) < 2e-4
+    ids = b["labels"][:, 1:]
+    valid = ids != -100
+    assert np.array_equal(pred_ids.numpy()[valid.numpy()], g[f"{mode}.discrete.predicted_ids"][valid.numpy()])
+    for name, mk in (("curr_action", vo.current_action_mask(ids, 7)), ("next_actions", vo.next_actions_mask(ids, 7))):
+        acc = ((pred_ids == ids) & mk).sum().item() / mk.sum().item()
+        assert abs(acc - float(g[f"{mode}.discrete.{name}_accuracy"])) < 1e-7
+        dec = lambda t: vo.decode_token_ids_to_actions(t[mk].numpy())  # noqa: E731
+        assert abs(np.abs(dec(pred_ids) - dec(ids)).mean() - float(g[f"{mode}.discrete.{name}_l1_loss"])) < 1e-9
+
+
+def test_g21_run_forward_pass_diffusion_objective_matches_reference():
+    """Diffusion objective (finetune.py:327-333, 402-407): the reference drew noise / timesteps, noised the bf16 actions through `add_noise`, ran the VLM
+    with the timestep token and the projected noisy actions in the action slots (FiLM on) and took the MSE of the bf16 noise prediction."""
+    g = load("g21_ref_run_forward_pass.npz")
+    sd = _ref_sd(g, diffusion=True)
+    noise, ts = torch.from_numpy(g["diffusion.noise"]), torch.from_numpy(g["diffusion.timesteps"])
+    ddim = vo.DDIM(int(g["diffusion.T"]))
+    gt16 = torch.from_numpy(g["actions"]).to(torch.bfloat16).float()
+    noisy = ddim.add_noise(gt16, noise, ts).to(torch.bfloat16).float()
+    assert np.array_equal(noisy.numpy(), g["diffusion.noisy_actions"]), "x_t = add_noise(actions, noise, t) on the recorded draws"
+    cfg, b, o32, o16, ah16, P = _g21_parts(g, "bidirectional", sd, diffusion=dict(noisy=noisy, timesteps=ts))
+    with torch.no_grad():
+        eps = o16.noise_head(ah16).reshape(noise.shape)
+        loss = float(o16.R(((eps - noise) ** 2).mean()))
+    ref = float(g["diffusion.loss"])
+    assert abs(loss - ref) <= 1.5e-2 * ref, (loss, ref)

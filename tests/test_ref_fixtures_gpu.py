@@ -223,3 +223,66 @@ def test_g19_diffusion_predict_action_matches_reference_loop(dev, mode):
     eh = relmax(ah.float().cpu().numpy(), g[f"{mode}.film.predict.p.diffusion.hidden"])
     print(f"G19 diffusion {mode}: actions L-inf {e:.3e}, last-step hidden rel-max {eh:.3e}")
     assert e < 0.1 and eh < 6e-2
+
+
+@pytest.mark.parametrize("mode", ["bidirectional", "causal"])
+def test_g21_run_forward_pass_matches_reference(dev, mode):
+    """The mirror's `run_forward_pass` (openvla-oft_amd/vla_scripts/finetune.py; HIP engine behind the autograd bridge) against the reference's own function
+    executed in the build container (vla-scripts/finetune.py:280-451, fixture G21): L1-regression loss + current / next action L1 metrics, and the discrete
+    objective's cross entropy + token accuracies + decoded L1."""
+    from tests.duck_tokenizer import DuckTokenizer
+
+    g = fixture("g21_ref_run_forward_pass.npz")
+    modeling, ft, AT = load("openvla-oft_amd.modeling"), load("openvla-oft_amd.vla_scripts.finetune"), load("openvla-oft_amd.prismatic.vla.action_tokenizer")
+    vla, cfg, sd, sub, pp = build(dev, g, mode, False)
+    head = modeling.L1RegressionActionHead(cfg.llm_dim, cfg.llm_dim, 7, device=dev, state_dict=sub("action_head."))
+    batch = {k: torch.from_numpy(g[k]) for k in ("input_ids", "attention_mask", "labels", "pixel_values", "proprio", "actions")}
+    tok = AT.ActionTokenizer(DuckTokenizer())
+    P = 2 * cfg.dino.n_patches + 1
+    with torch.no_grad():
+        loss, m = ft.run_forward_pass(vla, head, None, pp, batch, tok, dev, True, False, True, False, P)
+    ref = float(g[f"{mode}.l1.loss"])
+    print(f"G21 {mode}: L1 loss hip {float(loss):.4f} reference {ref:.4f}; curr {m['curr_action_l1_loss']:.4f} / {float(g[f'{mode}.l1.curr_action_l1_loss']):.4f}")
+    assert abs(float(loss) - ref) <= 3e-2 * ref
+    assert abs(m["curr_action_l1_loss"] - float(g[f"{mode}.l1.curr_action_l1_loss"])) <= 6e-2 and abs(m["next_actions_l1_loss"] - float(g[f"{mode}.l1.next_actions_l1_loss"])) <= 3e-2
+    # discrete objective: lm_head with the fixture's boosted action rows
+    sd_d = dict(ref_sd(g))
+    lm = sd_d["language_model.lm_head.weight"].clone()
+    lm[31744:32000] *= float(g["lm_action_gain"])
+    sd_d["language_model.lm_head.weight"] = lm
+    sd_d = {k: v for k, v in sd_d.items() if ".scale." not in k and ".shift." not in k}
+    config_mod = load("openvla-oft_amd.config")
+    cfg_d = config_mod.VLAConfig.from_any(vo.tiny_config())
+    cfg_d.mask_mode = mode
+    vla_d = modeling.OpenVLAForActionPrediction(cfg_d, sd_d, device=dev, lora=False, use_film=False)
+    with torch.no_grad():
+        loss_d, md = ft.run_forward_pass(vla_d, None, None, pp, batch, tok, dev, False, False, True, False, P)
+    ref_d = float(g[f"{mode}.discrete.loss"])
+    print(f"G21 {mode}: CE hip {float(loss_d):.4f} reference {ref_d:.4f}; decoded L1 curr {md['curr_action_l1_loss']:.4f} / {float(g[f'{mode}.discrete.curr_action_l1_loss']):.4f}")
+    assert abs(float(loss_d) - ref_d) <= 2e-2 * ref_d
+    for k in ("curr_action_accuracy", "next_actions_accuracy"):
+        assert abs(md[k] - float(g[f"{mode}.discrete.{k}"])) <= 0.03
+    for k in ("curr_action_l1_loss", "next_actions_l1_loss"):
+        assert abs(md[k] - float(g[f"{mode}.discrete.{k}"])) <= 0.08, (k, md[k], float(g[f"{mode}.discrete.{k}"]))
+
+
+def test_g21_run_forward_pass_diffusion_matches_reference(dev):
+    """The diffusion branch of the mirror's run_forward_pass on the reference's recorded draws (noise, x_t, timesteps): noise-prediction MSE."""
+    from tests.duck_tokenizer import DuckTokenizer
+
+    g = fixture("g21_ref_run_forward_pass.npz")
+    modeling, ft, AT = load("openvla-oft_amd.modeling"), load("openvla-oft_amd.vla_scripts.finetune"), load("openvla-oft_amd.prismatic.vla.action_tokenizer")
+    vla, cfg, sd, sub, pp = build(dev, g, "bidirectional", True, diffusion=True)
+    T = int(g["diffusion.T"])
+    head = modeling.DiffusionActionHead(cfg.llm_dim, cfg.llm_dim, 7, num_diffusion_steps=T, device=dev, state_dict=sub("action_head."))
+    nap = modeling.NoisyActionProjector(cfg.llm_dim, device=dev, state_dict=sub("noisy_action_projector."))
+    noise, noisy, ts = torch.from_numpy(g["diffusion.noise"]), torch.from_numpy(g["diffusion.noisy_actions"]), torch.from_numpy(g["diffusion.timesteps"])
+    temb = head.time_encoder(ts.float()).to(BF).unsqueeze(1)
+    head.sample_noisy_actions = lambda gt, generator=None: dict(noise=noise.to(BF), noisy_actions=noisy.to(BF), diffusion_timestep_embeddings=temb, timesteps=ts)
+    batch = {k: torch.from_numpy(g[k]) for k in ("input_ids", "attention_mask", "labels", "pixel_values", "proprio", "actions")}
+    P = 2 * cfg.dino.n_patches + 2
+    with torch.no_grad():
+        loss, m = ft.run_forward_pass(vla, head, nap, pp, batch, AT.ActionTokenizer(DuckTokenizer()), dev, False, True, True, True, P, compute_diffusion_l1=False, num_diffusion_steps=T)
+    ref = float(g["diffusion.loss"])
+    print(f"G21 diffusion: MSE hip {float(loss):.4f} reference {ref:.4f}")
+    assert abs(float(loss) - ref) <= 4e-2 * ref
