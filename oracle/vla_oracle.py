@@ -14,7 +14,14 @@ Pinning status (see DESIGN.md "Oracle"):
     restated from the reference call sites: PARITY UNPINNED against timm itself;
   * LoRA: pinned against plain torch autograd (G8); peft 0.11.1 itself absent.  DDIM (diffusers absent): PARITY UNPINNED, restated from the
     library's published algorithm;
-  * the JPEG round trip (oracle/jpeg_oracle.py): pinned bit-exactly against libjpeg-turbo (G12).
+  * the JPEG round trip (oracle/jpeg_oracle.py): pinned bit-exactly against libjpeg-turbo (G12);
+  * since round 3 the model-level logic -- projector, FiLM block, vision backbones (which block, prefix drop, concat order, language average),
+    action masks / embedding replacement / multimodal concat, `forward` (L1, diffusion inputs, FiLM, both mask modes, logits, CE loss),
+    `predict_action` (L1, discrete, diffusion loop), `RLDSBatchTransform`, `run_forward_pass` (all three objectives + metrics) -- is pinned against
+    the reference's OWN files EXECUTED in the build container: prismatic/extern/hf/modeling_prismatic.py, prismatic/models/film_vit_wrapper.py,
+    prismatic/vla/datasets/datasets.py, vla-scripts/finetune.py (fixtures G16-G21; tests/golden/make_golden_ref_model.py,
+    make_golden_batch_transform.py, make_golden_run_forward_pass.py).  Still restated from text only: experiments/robot/openvla_utils.py's TF image ops
+    and processing_prismatic.py (TensorFlow / torchvision absent).
 
 Every function cites the reference file:line (relative to the reference root) it follows.
 
