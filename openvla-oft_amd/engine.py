@@ -49,6 +49,8 @@ _FUSE_ACT, _FUSE_SWIGLU = _FUSE in ("act", "all"), _FUSE in ("swiglu", "all")
 # barrier needs every workgroup resident at once: the launch is refused otherwise, a timed-out spin poisons every output with NaN and sets a
 # sticky word that ActionHead.check_fused_tail() turns into an exception at the step's host sync.
 _FUSE_HEAD = {"0": False, "1": True}.get(os.environ.get("OVLA_FUSE_HEAD", "auto"), None)
+# OVLA_ASYNC_UPLOAD=0: upload ids / labels / lengths with synchronous pageable copies as before (A/B switch of VLAEngine.forward's pinned upload)
+_ASYNC_UPLOAD = os.environ.get("OVLA_ASYNC_UPLOAD", "1") != "0"
 # OVLA_FOLD_RMSNORM=0: keep the decoder's RMSNorms as their own launches on the merged inference path (A/B switch of LlamaStack.fold_norms).
 _FOLD_RMSNORM = os.environ.get("OVLA_FOLD_RMSNORM", "1") != "0"
 # OVLA_LORA_BWD=1: the LoRA backward's dt and dB from ONE pass over dy (csrc/lora_bwd.hip) instead of a skinny NT GEMM (dt) + TN GEMMs (dB, dA).
@@ -1080,10 +1082,21 @@ class VLAEngine:
         are computed (LlamaStack.fwd) and returned as `action_hidden` [n, D]; `hidden` is then None."""
         dev = self.device
         B, L = input_ids.shape
-        ids = input_ids.to(dev, torch.int64).contiguous()
-        lab = labels.to(dev, torch.int64).contiguous()
         lens = self.check_right_padding(attention_mask)
-        return self.forward_dev(ids, lab, lens.to(torch.int32).to(dev), pixel_values, proprio=proprio, noisy_actions=noisy_actions,
+        if input_ids.is_cuda or labels.is_cuda or not _ASYNC_UPLOAD:
+            ids = input_ids.to(dev, torch.int64).contiguous()
+            lab = labels.to(dev, torch.int64).contiguous()
+            lens_dev = lens.to(torch.int32).to(dev)
+        else:
+            # ONE asynchronous upload per step from pinned memory (ids | labels | lengths packed): a pageable `.to(device)` is a synchronous copy
+            # queued behind the whole previous step, so the host re-joined the GPU at every step boundary and started the ~3500 launches of the next
+            # step from zero lead -- during the towers' 10-25 us kernels the GPU then ran at the host's launch rate.  PyTorch's caching host
+            # allocator keeps the pinned block alive until the copy has completed.
+            packed = torch.cat([input_ids.reshape(-1).to(torch.int64), labels.reshape(-1).to(torch.int64), lens.reshape(-1).to(torch.int64)]).pin_memory()
+            packed_dev = packed.to(dev, non_blocking=True)
+            ids, lab = packed_dev[: B * L].view(B, L), packed_dev[B * L: 2 * B * L].view(B, L)
+            lens_dev = packed_dev[2 * B * L:].to(torch.int32)
+        return self.forward_dev(ids, lab, lens_dev, pixel_values, proprio=proprio, noisy_actions=noisy_actions,
                                 timestep_emb=timestep_emb, train=train, proprio_projector=proprio_projector,
                                 noisy_action_projector=noisy_action_projector, cached_patches=cached_patches, sel=sel)
 

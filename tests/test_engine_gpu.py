@@ -199,3 +199,37 @@ def test_last_layer_on_selected_rows_equals_the_full_forward(setup):
     worst = max((((g_sel[k].float() - g_full[k]).norm() / (g_full[k].norm() + 1e-12)).item(), k) for k in g_full if g_full[k].norm() > 1e-7)
     print(f"selected-rows backward vs full backward: worst rel-L2 {worst[0]:.3e} ({worst[1]})")
     assert worst[0] < 2e-2
+
+
+def test_async_pinned_upload_equals_the_synchronous_one(dev):
+    """VLAEngine.forward uploads ids | labels | lengths as ONE non-blocking copy from pinned memory (the host no longer re-joins the GPU at every step):
+    back-to-back forwards on DIFFERENT batches, each behind a long-running kernel queue, must give exactly what the synchronous pageable copies give
+    (the pinned staging block of call k must survive until its copy has run, although call k + 1 has long been enqueued)."""
+    import importlib
+
+    load = importlib.import_module
+    engine_mod, weights_mod, config_mod, synth = load("openvla-oft_amd.engine"), load("openvla-oft_amd.weights"), load("openvla-oft_amd.config"), load("openvla-oft_amd.synthetic")
+    ocfg = vo.tiny_config()
+    cfg = config_mod.VLAConfig.from_any(ocfg)
+    get, has = weights_mod.make_getter(vo.random_state_dict(ocfg, seed=0), dev)
+    eng = engine_mod.VLAEngine(cfg, get, dev, lora=True, use_proprio=True, head="l1", has=has)
+    batches = [synth.make_batch(2, seed=50 + i, prompt_lens=[9, 7 + (i % 3)], image_size=56) for i in range(6)]
+    busy = torch.randn(4096, 4096, device=dev)
+
+    def run(async_on):
+        engine_mod._ASYNC_UPLOAD = async_on
+        outs = []
+        for b in batches:
+            for _ in range(20):
+                busy @ busy                                  # a queue of work ahead of the upload, so the copy executes long after forward() returned
+            o = eng.forward(b["input_ids"], b["attention_mask"], b["pixel_values"].to(dev, torch.bfloat16), b["labels"], proprio=b["proprio"].to(dev, torch.bfloat16), train=False)
+            outs.append((o["hidden"], o["action_rows"]))
+        torch.cuda.synchronize()
+        return [(h.clone(), r.clone()) for h, r in outs]
+
+    try:
+        a, s = run(True), run(False)
+    finally:
+        engine_mod._ASYNC_UPLOAD = True
+    for (ha, ra), (hs, rs) in zip(a, s):
+        assert torch.equal(ra, rs) and torch.equal(ha, hs)
