@@ -246,6 +246,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+#ifdef OVLA_GEMM_STAMPS   // in-kernel timeline (100 MHz wall clock) of a plain launch into the unused workspace: tools/gemm_stamps.py
+#define OVLA_STAMP(k) do { if (tid == 0) reinterpret_cast<unsigned long long*>(p.ws)[(int64_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define OVLA_STAMP(k) do { } while (0)
+#endif
+  OVLA_STAMP(0);
 
   // ---- block -> work unit ------------------------------------------------------------------------------------
   // Plain / split-K launch: blocks [0, tiles*splits) ; block ids are remapped so each XCD (private L2) owns a contiguous
@@ -257,7 +263,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   const int remap_n = p.rem_tiles > 0 ? p.full_tiles : (int)gridDim.x;
   int split = 0, t_mn, rem_unit = -1;
   if (bid < remap_n) {
+#ifdef OVLA_XCD_ROT   // experiment: give physical XCD x the band of XCD (x + ROT) & 7 -- does a slow band follow the silicon or the data?
+    const int xcd = ((bid & 7) + OVLA_XCD_ROT) & 7, q = remap_n >> 3, r = remap_n & 7;
+#else
     const int xcd = bid & 7, q = remap_n >> 3, r = remap_n & 7;
+#endif
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     split = bid / tiles_mn;
     t_mn = bid - split * tiles_mn;
@@ -376,6 +386,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     const int buf = (t - t_begin) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA for tile t has landed
     __syncthreads();                                   // ... everyone's has; and buf^1 is no longer being read
+#ifdef OVLA_GEMM_STAMPS
+    if (t == t_begin) OVLA_STAMP(2);
+#endif
     if constexpr (!SPREAD) {
       if (t + 1 < t_end && !(OVLA_DBG(1) && t > t_begin)) stage(t + 1, buf ^ 1);
     }
@@ -438,6 +451,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
     __builtin_amdgcn_s_setprio(0);
   };
 
+  OVLA_STAMP(1);
   if (t_begin < t_end) stage(t_begin, 0);
   // (the fold's prologue loads are issued AFTER the first K tile's LDS-DMA, so the two latencies overlap: issued first, their wait delayed the DMA by a
   // whole memory round trip -- measured: the removed norm launches' time came back inside the GEMMs)
@@ -477,6 +491,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   for (int j = 0; j < NT; ++j)
     acc[MT - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a_def, acc[MT - 1][j], 0, 0, 0);
 
+  OVLA_STAMP(3);
   if (OVLA_DBG(8)) {   // timing ablation: no epilogue at all (one store per lane keeps the accumulators alive)
     if (acc[0][0][0] == 123.456f) p.C[0] = 1;
     return;
@@ -704,6 +719,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (reads consumed above; keeps the next round's writes behind them)
     }
+#ifdef OVLA_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's stores have been acknowledged
+    OVLA_STAMP(4);
+#endif
     return;
   }
   // General path (activations, pre-activation save, LayerScale, FiLM, backward epilogues, RoPE, edge tiles): one rolled loop.
