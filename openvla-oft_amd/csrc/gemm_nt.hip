@@ -768,6 +768,356 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   }
 }
 
+// ---- experiment: 256x256 tile on FOUR waves (one per SIMD, 128x128 per wave, 256 accumulator registers in AGPRs), register-staged operands ------
+// The 8-wave kernel above reads (128 + 64) fragment rows per wave and K step from LDS (192 KB per K tile and CU) and pays 60-150 cycles of issue per
+// LDS-DMA piece; its ablations put the staging at 13 % and the fragment reads at 9 % of the loop.  Four 128x128 waves read 128 KB per K tile, and with
+// one wave per SIMD nothing but that wave's own instruction stream can fill the MFMA shadows -- so operands come by plain global_load_dwordx4 into
+// registers (a few cycles of issue each) and go to LDS by ds_write_b128, one of each per MFMA row, one K tile ahead.  The compiler cannot hold 256
+// accumulators + 170 live VGPRs through its own scheduling (it rotates the accumulators through copies and spills: 736 v_accvgpr moves and 267
+// scratch stores per K tile were measured in its listing), so the K loop is written out instruction by instruction in inline asm: the accumulators
+// are tied AGPR operands ("+a"), every wait count is explicit (all memory operations of the loop are in the asm, in program order, so the counts are
+// constants).  K % 64 == 0, no K-extension.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+OVLA_DEV f32x4 w4_mfma(f32x4 acc, bf16x8_bits x, bf16x8_bits y) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(y)); return acc; }
+OVLA_DEV f32x4 w4_mfma0(bf16x8_bits x, bf16x8_bits y) { f32x4 acc; asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(x), "v"(y)); return acc; }
+template <int OFF> OVLA_DEV bf16x8_bits w4_ds_read(uint32_t addr) { bf16x8_bits dst; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF)); return dst; }
+template <int OFF> OVLA_DEV void w4_ds_write(uint32_t addr, u32x4 src) { asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(addr), "v"(src), "n"(OFF)); }
+OVLA_DEV f32x4 w4_pin(f32x4 v) { asm volatile("" : "+a"(v)); return v; }
+OVLA_DEV void w4_keep(u32x4 v) { asm volatile("" : : "v"(v)); }
+OVLA_DEV u32x4 w4_gload(uint32_t voff, const char* sbase) { u32x4 dst; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase)); return dst; }
+template <bool KEXT>
+__global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, WTM = 128, WTN = 128, MT = 8, NT = 8;
+  constexpr int TILE_BYTES = (BM + BN) * BK * 2;   // 65536
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  OVLA_STAMP(0);
+
+  int bid = blockIdx.x;
+  const int tiles_mn = p.tiles_m * p.tiles_n;
+  const int remap_n = p.rem_tiles > 0 ? p.full_tiles : (int)gridDim.x;
+  int split = 0, t_mn, rem_unit = -1;
+  if (bid < remap_n) {
+    const int xcd = bid & 7, q = remap_n >> 3, r = remap_n & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    split = bid / tiles_mn;
+    t_mn = bid - split * tiles_mn;
+  } else {
+    int u = bid - p.full_tiles;
+    const int nrem = p.rem_tiles * p.rem_splits;
+    const int xcd = u & 7, q = nrem >> 3, r = nrem & 7;
+    u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (u >> 3);
+    split = u / p.rem_tiles;
+    const int rt = u - split * p.rem_tiles;
+    t_mn = p.full_tiles + rt;
+    rem_unit = rt * p.rem_splits + split;
+  }
+  constexpr int GROUP = 8;
+  const int group_sz = GROUP * p.tiles_n;
+  const int gid = t_mn / group_sz;
+  const int first_m = gid * GROUP;
+  const int gm = (p.tiles_m - first_m) < GROUP ? (p.tiles_m - first_m) : GROUP;
+  const int in_group = t_mn - gid * group_sz;
+  const int tm = first_m + in_group % gm;
+  const int tn = in_group / gm;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int T = p.T1;
+  int t_begin = 0, t_end = T;
+  const int nsplit = rem_unit >= 0 ? p.rem_splits : p.split_k;
+  if (nsplit > 1) {
+    const int chunk = (T + nsplit - 1) / nsplit;
+    t_begin = split * chunk;
+    t_end = t_begin + chunk < T ? t_begin + chunk : T;
+  }
+
+  f32x4 acc[MT][NT];
+  if constexpr (!KEXT)   // (with a K-extension its MFMAs are the first to touch every accumulator and take the constant 0 as their C operand)
+    static_for<MT * NT>([&](auto e_tag) { constexpr int e = decltype(e_tag)::value; acc[e / NT][e % NT] = w4_pin(f32x4{0.f, 0.f, 0.f, 0.f}); });   // pinned: left to itself the compiler keeps the zeros as constants and merges them into the loop through scratch
+
+  // staging: piece i of this wave = rows (wave * 8 + i) * 8 .. + 7 of the A (i < 8) / B (i >= 8) tile; lane -> row + (lane >> 3), 16-byte chunk lane & 7
+  // (eight lanes read one row's 128 contiguous bytes); the LDS image is the 8-wave kernel's (chunk XOR (row >> 1) & 7), applied on the WRITE address.
+  uint32_t offA[8], offB[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int r = (wave * 8 + i) * 8 + (lane >> 3);
+    int ga = m0 + r, gb = n0 + r;
+    ga = ga < p.M - 1 ? ga : p.M - 1;
+    gb = gb < p.N - 1 ? gb : p.N - 1;
+    offA[i] = (uint32_t)(((int64_t)ga * p.lda + (lane & 7) * 8) * 2);
+    offB[i] = (uint32_t)(((int64_t)gb * p.ldb + (lane & 7) * 8) * 2);
+  }
+  // LDS byte addresses (VGPRs); the piece / m-tile index goes into the instruction's offset field
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;   // LDS addresses are 32-bit (the pointer's low word)
+  const int wx = (lane & 7) ^ (lane >> 4);               // (r >> 1) & 7 = (4 (i & 1) + (lane >> 4)) & 7 for r = 8 (8 wave + i) + (lane >> 3)
+  const uint32_t w_even = lds0 + wave * 8192 + (lane >> 3) * 128 + wx * 16, w_odd = lds0 + wave * 8192 + (lane >> 3) * 128 + (wx ^ 4) * 16;
+  uint32_t wr[2][2] = {{w_even, w_odd}, {w_even + TILE_BYTES, w_odd + TILE_BYTES}};   // [buffer][piece parity]
+  const int arow = wm * WTM + (lane & 15), brow = wn * WTN + (lane & 15), cq = lane >> 4;
+  const uint32_t ra0 = lds0 + arow * 128 + ((cq ^ ((arow >> 1) & 7)) * 16), rb0 = lds0 + BM * 128 + brow * 128 + ((cq ^ ((brow >> 1) & 7)) * 16);
+  uint32_t ra[2][2] = {{ra0, ra0 ^ 64}, {ra0 + TILE_BYTES, (ra0 ^ 64) + TILE_BYTES}};   // [buffer][k substep]: + 2048 i per m-tile in the offset field
+  uint32_t rb[2][2] = {{rb0, rb0 ^ 64}, {rb0 + TILE_BYTES, (rb0 ^ 64) + TILE_BYTES}};
+
+  u32x4 g[16];
+  bf16x8_bits b0[NT], b1[NT], a_cur, a_nxt;
+  bf16x8_bits a_def = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < NT; ++j) b1[j] = a_def;
+
+  auto clampt = [&](int t) { return t < t_end ? t : t_end - 1; };
+  auto tile_base = [&](const bf16_bits* base, int t) {   // wave-uniform by construction; said explicitly, because the asm loads take it as an SGPR pair ("s")
+    const uint64_t a = reinterpret_cast<uint64_t>(base) + (uint64_t)((int64_t)t * (BK * 2));
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    // Both halves are materialised in SGPRs HERE, five wait states before any asm load can use them: when the compiler takes the tile index for
+    // divergent (seen with the stamp build's `if (tid == 0)` stores) the halves come from v_readfirstlane, and an SGPR written by a VALU instruction
+    // needs 5 wait states before a vector memory instruction reads it -- a hazard the compiler cannot see inside inline asm (it faulted the GPU once).
+    asm volatile("s_nop 4" : "+s"(lo), "+s"(hi));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+  };
+  // prologue.  (1) K-extension (LoRA: K2 = 32 or 64, one or two MFMA k-steps): its fragments come straight from global memory (16 bytes per lane and
+  // fragment, rows 64 / 128 bytes wide), issued FIRST.  (2) K tile t_begin goes to LDS buffer 0 by LDS-DMA (the only DMA of the kernel: no register round
+  // trip for the tile everything waits on; source chunk = slot XOR (row >> 1) & 7 as in the 8-wave kernel).  (3) The K-extension's 64 MFMAs per k-step run
+  // while that tile is on its way.  (4) Tile t_begin + 1 into the staging registers, in the loop's order.  The compiler counts the vector memory operations
+  // it knows (1, 2) when it waits for (1) before (3); the asm loads of (4) are invisible to it, so none of them may be issued before (3).
+  OVLA_STAMP(1);
+  bf16x8_bits a2f[KEXT ? MT : 1], b2f[KEXT ? NT : 1];
+  if constexpr (KEXT) {   // K2 == 32 (host-checked).  Straight-line code: a branch around asm that updates 64 accumulators makes the compiler merge them through scratch
+    const int a2_col0 = p.k2_group_n > 0 ? (n0 / p.k2_group_n) * p.K2 : 0;
+    const bf16_bits* a2p = p.A2 + a2_col0 + 8 * cq;
+    const bf16_bits* b2p = p.B2 + 8 * cq;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { int m = m0 + arow + i * 16; m = m < p.M - 1 ? m : p.M - 1; a2f[i] = *reinterpret_cast<const bf16x8_bits*>(a2p + (int64_t)m * p.lda2); }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { int n = n0 + brow + j * 16; n = n < p.N - 1 ? n : p.N - 1; b2f[j] = *reinterpret_cast<const bf16x8_bits*>(b2p + (int64_t)n * p.ldb2); }
+  }
+  {
+    const char* gA = tile_base(p.A, clampt(t_begin));
+    const char* gB = tile_base(p.B, clampt(t_begin));
+    const int sw = lane >> 4, c = lane & 7;
+    const int d_even = ((c ^ sw) - c) * 16, d_odd = ((c ^ sw ^ 4) - c) * 16;   // source chunk of LDS slot (lane & 7) in piece i: slot XOR (4 (i & 1) + (lane >> 4))
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + (int64_t)offA[i] + ((i & 1) ? d_odd : d_even)),
+                                       (__attribute__((address_space(3))) void*)(smem_raw + (wave * 8 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + (int64_t)offB[i] + ((i & 1) ? d_odd : d_even)),
+                                       (__attribute__((address_space(3))) void*)(smem_raw + BM * 128 + (wave * 8 + i) * 1024), 16, 0, 0);
+    }
+  }
+  if constexpr (KEXT) {
+    if (t_begin != 0) {   // a later K part of a split tile: the extension belongs to the first part only
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a2f[i] = bf16x8_bits{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    static_for<MT * NT>([&](auto e_tag) { constexpr int i = decltype(e_tag)::value / NT, j = decltype(e_tag)::value % NT; acc[i][j] = w4_mfma0(b2f[j], a2f[i]); });
+  }
+  {
+    const char* hA = tile_base(p.A, clampt(t_begin + 1));
+    const char* hB = tile_base(p.B, clampt(t_begin + 1));
+    g[15] = w4_gload(offB[7], hB);   // the loop's order: piece 15 at the top of a body, then 0 .. 14 with the rows
+    static_for<8>([&](auto i_tag) { constexpr int i = decltype(i_tag)::value; g[i] = w4_gload(offA[i], hA); });
+    static_for<7>([&](auto i_tag) { constexpr int i = decltype(i_tag)::value; g[8 + i] = w4_gload(offB[i], hB); });
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the 16 LDS-DMA pieces of tile t_begin have landed (the 16 register loads behind them may still fly)
+  }
+
+  // body t (PAR = parity of t - t_begin = LDS buffer holding tile t).  Program order of memory operations per MFMA row r (0 .. 15; row 15 of tile t - 1 is
+  // the deferred row issued at the top): ds_read a(r + 1) [+ ds_read b1[i] in the first k substep], vmcnt(15) + ds_write piece r of tile t + 1 into the
+  // other buffer, global_load piece r of tile t + 2 into the freed registers, lgkmcnt(n) for a(r), 8 MFMAs.  16 loads are in flight per wave at all
+  // times, so `vmcnt(15)` is exactly "the load issued 16 loads ago has landed".
+  // (STAGE = false: the odd last tile, after which nothing is staged any more.  A staging load whose result is never used would be a DEAD asm output: the
+  // compiler then hands its destination registers to the next live value while the load is still in flight -- seen in the listing, half a K tile lost.)
+  auto body = [&](const int t, auto par_tag, auto stage_tag) {
+    constexpr int PAR = decltype(par_tag)::value;
+    constexpr bool STAGE = decltype(stage_tag)::value;
+    const char* gA = tile_base(p.A, clampt(t + 2));
+    const char* gB = tile_base(p.B, clampt(t + 2));
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier");   // tile t is in LDS (everyone's ds_writes), nobody reads the other buffer any more
+    static_for<NT>([&](auto j_tag) { constexpr int j = decltype(j_tag)::value; b0[j] = w4_ds_read<j * 2048>(rb[PAR][0]); });
+    a_cur = w4_ds_read<0>(ra[PAR][0]);
+    if constexpr (STAGE) {
+      asm volatile("s_waitcnt vmcnt(15)");
+      w4_ds_write<7 * 1024 + BM * 128>(wr[PAR ^ 1][1], g[15]);
+      g[15] = w4_gload(offB[7], gB);
+    }
+    asm volatile("s_setprio 1");
+    static_for<NT>([&](auto j_tag) { constexpr int j = decltype(j_tag)::value; acc[MT - 1][j] = w4_mfma(acc[MT - 1][j], b1[j], a_def); });   // deferred row of tile t - 1
+    static_for<2 * MT - 1>([&](auto r_tag) {
+      constexpr int r = decltype(r_tag)::value;
+      constexpr int sub = r / MT, i = r % MT;
+      constexpr int rn = r + 1, subn = rn / MT, in_ = rn % MT;
+      a_nxt = w4_ds_read<in_ * 2048>(ra[PAR][subn]);
+      if constexpr (sub == 0) b1[i] = w4_ds_read<i * 2048>(rb[PAR][1]);
+      if constexpr (STAGE) {
+        asm volatile("s_waitcnt vmcnt(15)");
+        w4_ds_write<(r & 7) * 1024 + (r < 8 ? 0 : BM * 128)>(wr[PAR ^ 1][r & 1], g[r]);
+        if constexpr (r < 8) g[r] = w4_gload(offA[r], gA);
+        else g[r] = w4_gload(offB[r - 8], gB);
+      }
+      // a(r) is the FIRST LDS operation of row r - 1 (a(0): of the top, before the top's ds_write); everything issued after it may stay in flight:
+      // row r - 1's [b1 read] and ds_write, this row's a(r + 1), [b1 read] and ds_write.  (The b fragments a row uses are older than its a fragment.)
+      // (row MT, the first of the second k substep, also needs b1[MT - 1], which row MT - 1 issued right AFTER a(MT))
+      constexpr int newer = (r == 0 ? (STAGE ? 4 : 2) : sub == 0 ? (STAGE ? 5 : 3) : (STAGE ? 3 : 1));
+      asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(newer));
+      static_for<NT>([&](auto j_tag) {
+        constexpr int j = decltype(j_tag)::value;
+        if constexpr (sub == 0) acc[i][j] = w4_mfma(acc[i][j], b0[j], a_cur);
+        else acc[i][j] = w4_mfma(acc[i][j], b1[j], a_cur);
+      });
+      a_cur = a_nxt;
+    });
+    a_def = a_cur;
+    asm volatile("s_setprio 0");
+  };
+  int t = t_begin;
+  OVLA_STAMP(2);
+  for (; t + 1 < t_end; t += 2) {
+    body(t, std::integral_constant<int, 0>{}, std::true_type{});
+    body(t + 1, std::integral_constant<int, 1>{}, std::true_type{});
+  }
+  if (t < t_end) body(t, std::integral_constant<int, 0>{}, std::false_type{});
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  static_for<16>([&](auto q_tag) { w4_keep(g[decltype(q_tag)::value]); });   // the staging registers stay allocated until their last loads have landed
+  static_for<NT>([&](auto j_tag) { constexpr int j = decltype(j_tag)::value; acc[MT - 1][j] = w4_mfma(acc[MT - 1][j], b1[j], a_def); });
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // the compiler's hazard recognizer does not see the asm MFMAs' AGPR writes
+  OVLA_STAMP(3);
+
+  // (compile-time indices everywhere: one dynamically indexed use would keep the accumulator array in scratch memory, written through after every MFMA)
+  if (rem_unit >= 0) {
+    float* slab = p.ws + (int64_t)rem_unit * (BM * BN);
+    static_for<MT * NT>([&](auto e_tag) {
+      constexpr int i = decltype(e_tag)::value / NT, j = decltype(e_tag)::value % NT;
+      *reinterpret_cast<f32x4*>(slab + (wm * WTM + i * 16 + (lane & 15)) * BN + wn * WTN + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+    });
+    return;
+  }
+  if (p.split_k > 1) {
+    static_for<MT * NT>([&](auto e_tag) {
+      constexpr int i = decltype(e_tag)::value / NT, j = decltype(e_tag)::value % NT;
+      const int m = m0 + wm * WTM + i * 16 + (lane & 15), n = n0 + wn * WTN + j * 16 + 4 * (lane >> 4);
+      if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(p.ws + ((int64_t)split * p.M + m) * p.N + n) = acc[i][j];
+    });
+    return;
+  }
+  // accumulators -> wave-private fp32 LDS slab (two m-tiles = 32 rows x (128 + 4) per round, four rounds) -> read back in row order, 16 lanes per row,
+  // one 16-byte store per lane and step.  With one wave per SIMD nothing else hides the LDS and memory latencies: a round's eight read-back steps are all in
+  // flight together and its residual rows / RoPE table rows are requested BEFORE the slab round trip.  (Stores straight from the registers -- n-tiles
+  // permuted so that a lane's tile pair is 8 consecutive columns, 16 rows x 64 bytes per store instruction -- measured 7 % slower per tile than this.)
+  constexpr int LDSW = WTN + 4;
+  float* slab = reinterpret_cast<float*>(smem_raw) + wave * (32 * LDSW);
+  const int mbase = m0 + wm * WTM, nbase = n0 + wn * WTN;
+  __syncthreads();   // nobody reads the K tiles any more; from here on a wave touches only its own slab
+  auto to_slab = [&](auto rd_tag) {
+    constexpr int rd = decltype(rd_tag)::value;
+    static_for<2 * NT>([&](auto e_tag) {
+      constexpr int ii = decltype(e_tag)::value / NT, j = decltype(e_tag)::value % NT;
+      *reinterpret_cast<f32x4*>(slab + (ii * 16 + (lane & 15)) * LDSW + j * 16 + 4 * (lane >> 4)) = acc[rd * 2 + ii][j];
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;
+  if (p.rope_cos && nbase < p.rope_cols) {   // RoPE (head_dim 128 = this wave's 128 columns): the rotation partner of octet c8 is octet c8 ^ 8 of the same slab row
+    static_for<MT / 2>([&](auto rd_tag) {
+      constexpr int rd = decltype(rd_tag)::value;
+      bf16x8_bits csv[8], snv[8];
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int idx = st * 64 + lane, row = idx >> 4, c8 = idx & 15;
+        const int m = mbase + rd * 32 + row, cin = (c8 & 7) * 8;
+        const int pos = (m < p.M ? m : p.M - 1) % p.rope_S;
+        csv[st] = *reinterpret_cast<const bf16x8_bits*>(p.rope_cos + (int64_t)pos * 64 + cin);
+        snv[st] = *reinterpret_cast<const bf16x8_bits*>(p.rope_sin + (int64_t)pos * 64 + cin);
+      }
+      to_slab(rd_tag);
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        const int idx = st * 64 + lane, row = idx >> 4, c8 = idx & 15;
+        const float* xs = slab + row * LDSW + c8 * 8;
+        const float* ys = slab + row * LDSW + (c8 ^ 8) * 8;
+        const f32x4 xlo = *reinterpret_cast<const f32x4*>(xs), xhi = *reinterpret_cast<const f32x4*>(xs + 4);
+        const f32x4 ylo = *reinterpret_cast<const f32x4*>(ys), yhi = *reinterpret_cast<const f32x4*>(ys + 4);
+        const int m = mbase + rd * 32 + row, n = nbase + c8 * 8;
+        const bool upper = c8 >= 8;
+        const bf16x8_bits cs = csv[st], sn = snv[st];
+        bf16x8_bits o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {    // rope_kernel's arithmetic on y = bf16(acc): lo' = bf16(a c) + bf16(-b s), hi' = bf16(b c) + bf16(a s)
+          const float x = bfround((e < 4 ? xlo[e] : xhi[e - 4]) * p.alpha), y = bfround((e < 4 ? ylo[e] : yhi[e - 4]) * p.alpha);
+          const float cc = bf2f((bf16_bits)cs[e]), sv = bf2f((bf16_bits)sn[e]);
+          o[e] = (short)f2bf(upper ? bfround(x * cc) + bfround(y * sv) : bfround(x * cc) + bfround(-y * sv));
+        }
+        if (m < p.M && n < p.N) *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    });
+    return;
+  }
+  if (p.fast_epi && interior && p.act == OVLA_ACT_NONE && !p.Cpre && !p.colscale) {   // alpha, bias, residual: every Llama projection, forward and data-gradient
+    static_for<MT / 2>([&](auto rd_tag) {
+      constexpr int rd = decltype(rd_tag)::value;
+      constexpr int GRP = 8;
+      bf16x8_bits r8[GRP];
+      if (p.residual) {
+#pragma unroll
+        for (int s2 = 0; s2 < GRP; ++s2) {
+          const int idx = s2 * 64 + lane, row = idx >> 4, c8 = idx & 15;
+          r8[s2] = *reinterpret_cast<const bf16x8_bits*>(p.residual + (int64_t)(mbase + rd * 32 + row) * p.ldr + nbase + c8 * 8);
+        }
+      }
+      to_slab(rd_tag);
+      f32x4 lo[GRP], hi[GRP];
+#pragma unroll
+      for (int s2 = 0; s2 < GRP; ++s2) {
+        const int idx = s2 * 64 + lane, row = idx >> 4, c8 = idx & 15;
+        lo[s2] = *reinterpret_cast<const f32x4*>(slab + row * LDSW + c8 * 8);
+        hi[s2] = *reinterpret_cast<const f32x4*>(slab + row * LDSW + c8 * 8 + 4);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < GRP; ++s2) {
+        const int idx = s2 * 64 + lane, row = idx >> 4, c8 = idx & 15;
+        const int m = mbase + rd * 32 + row, n = nbase + c8 * 8;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] = lo[s2][e] * p.alpha; x[4 + e] = hi[s2][e] * p.alpha; }
+        if (p.bias) {
+          const bf16x8_bits b8 = *reinterpret_cast<const bf16x8_bits*>(p.bias + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = x[e] + bf2f((bf16_bits)b8[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = bfround(x[e]);
+        if (p.residual) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = bfround(x[e] + bf2f((bf16_bits)r8[s2][e]));
+        }
+        bf16x8_bits o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(x[e]);
+        *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    });
+#ifdef OVLA_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    OVLA_STAMP(4);
+#endif
+    return;
+  }
+  // general path (edge tiles, activations, pre-activation save, LayerScale, FiLM, backward epilogues): one rolled loop per round
+  static_for<MT / 2>([&](auto rd_tag) {
+    constexpr int rd = decltype(rd_tag)::value;
+    to_slab(rd_tag);
+#pragma unroll 1
+    for (int it = 0; it < 16; ++it) {
+      const int idx = it * 64 + lane, row = idx >> 5, c4 = idx & 31;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * LDSW + c4 * 4);
+      const int m = mbase + rd * 32 + row, n = nbase + c4 * 4;
+      if (m < p.M && n < p.N) epilogue_store(p, m, n, v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  });
+}
+
+
 // =====================================================================================================================
 // Skinny-N, short-K GEMM in ONE launch (the ViT LoRA projections t = s x A^T and dt = s dy B: N = 32, K 1k..4k, M ~ 4k): the tiled
 // split-K path needs two launches (GEMM + reduce), ~20 us of mostly launch / ramp latency for 9 MB of input.  Here one workgroup
@@ -1340,6 +1690,45 @@ int launch_pipe(GemmParams& p, hipStream_t stream) {
   return OVLA_OK;
 }
 
+template <bool KEXT>
+int launch_w4(GemmParams& p, hipStream_t stream, int64_t ws_bytes, bool hybrid) {
+  if (p.K % BK != 0 || p.K2 != (KEXT ? 32 : 0) || !p.fast_addr || p.a_group_n > 0 || p.rowsq_out || p.rowscale_part || (p.k2_group_n > 0 && (p.k2_group_n % 256) != 0)) {
+    ovla_set_error("ovla_gemm_bf16: the 4-wave 256x256 config needs K %% 64 == 0, a K-extension of 0 or 32 and no block-diagonal / RMSNorm-fold mode");
+    return OVLA_EINVAL;
+  }
+  p.tiles_m = cdiv(p.M, 256);
+  p.tiles_n = cdiv(p.N, 256);
+  const int splits = p.split_k > 1 ? p.split_k : 1;
+  const size_t lds = (size_t)2 * 512 * BK * sizeof(bf16_bits);
+  auto kern = gemm_nt_w4_kernel<KEXT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int tiles = p.tiles_m * p.tiles_n;
+  p.full_tiles = tiles; p.rem_tiles = 0; p.rem_splits = 1;
+  if (hybrid && splits == 1 && p.ws != nullptr) {
+    const HybridPlan pl = plan_hybrid(p.M, p.N, p.T1 + p.T2, tile_cfg(256, 256), ws_bytes / 4);   // (same plan as the 8-wave config; the K-extension is not a K tile here)
+    p.full_tiles = pl.full_tiles; p.rem_tiles = pl.rem_tiles; p.rem_splits = pl.rem_splits;
+  }
+  p.hyb_cnt = nullptr;
+  const unsigned nblk = p.rem_tiles > 0 ? (unsigned)(p.full_tiles + p.rem_tiles * p.rem_splits) : (unsigned)(tiles * splits);
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, stream, p);
+  OVLA_CHECK_LAUNCH("ovla_gemm_bf16(w4)");
+  if (p.rem_tiles > 0) {
+    hipLaunchKernelGGL((gemm_hybrid_reduce_kernel<256, 256>), dim3(256 * 256 / 4 / 256 / 4, p.rem_tiles), dim3(256), 0, stream, p);
+    OVLA_CHECK_LAUNCH("ovla_gemm_bf16(w4 hybrid reduce)");
+  } else if (splits > 1) {
+    const int64_t quads = (int64_t)p.M * (p.N / 4);
+    int blocks = cdiv(quads, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, p);
+    OVLA_CHECK_LAUNCH("ovla_gemm_bf16(w4 split-k reduce)");
+  }
+  return OVLA_OK;
+}
+
 }  // namespace
 
 extern "C" int ovla_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t K2, int32_t k2_group_n, int64_t workspace_bytes, int32_t* tile,
@@ -1477,7 +1866,10 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     // ... and on the 128x128 tile (2x2 waves; batch-1 inference, M = 608): one head per column tile, any M (edge rows are skipped in the read-back)
     const bool fused1 = (tile == 1 || tile == 101) && p.split_k <= 1 && rope_plain && (p.N % 128) == 0 && (a->rope_cols % 128) == 0 &&
                         (((uintptr_t)a->rope_cos | (uintptr_t)a->rope_sin | (uintptr_t)a->C) & 15) == 0 && (a->ldc % 8) == 0;
-    const bool fused = ((tile == 16 || tile == 116) && p.split_k <= 1) || fused17 || fused1;
+    // ... and on the 4-wave 256x256 config (one head per wave slab, any M)
+    const bool fused18 = (tile == 18 || tile == 118) && p.split_k <= 1 && rope_plain && (p.N % 128) == 0 && (a->rope_cols % 128) == 0 &&
+                         (((uintptr_t)a->rope_cos | (uintptr_t)a->rope_sin | (uintptr_t)a->C) & 15) == 0 && (a->ldc % 8) == 0;
+    const bool fused = ((tile == 16 || tile == 116) && p.split_k <= 1) || fused17 || fused1 || fused18;
     if (fused) {
       p.rope_cos = (const bf16_bits*)a->rope_cos; p.rope_sin = (const bf16_bits*)a->rope_sin;
     } else {
@@ -1511,6 +1903,8 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     case 116: return launch_cfg<256, 256, 4, 2>(p, stream, wsb, true);
     case 17: return launch_cfg<256, 256, 2, 4>(p, stream, wsb, hybrid);   // 2x4 waves (128x64 wave tiles)
     case 117: return launch_cfg<256, 256, 2, 4>(p, stream, wsb, true);
+    case 18: return p.K2 > 0 ? launch_w4<true>(p, stream, wsb, false) : launch_w4<false>(p, stream, wsb, false);   // 4-wave 256x256, register-staged operands, hand-scheduled K loop
+    case 118: return p.K2 > 0 ? launch_w4<true>(p, stream, wsb, true) : launch_w4<false>(p, stream, wsb, true);
     case 101: return launch_cfg<128, 128, 2, 2>(p, stream, wsb, true);
     case 102: return launch_cfg<64, 128, 1, 4>(p, stream, wsb, true);
     case 105: return launch_cfg<128, 32, 4, 1>(p, stream, wsb, true);
