@@ -113,6 +113,8 @@ typedef struct {
 
 /* The schedule `tile = 0` would pick for a dense GEMM (no skinny / small-M special case): tile id (17 = 256x256, 1 = 128x128,
  * 2 = 64x128, 5 = 128x32), how many tiles run whole, how many are split along K and how many ways, and the cost model's estimate.
+ * (A launch that resolves to 17 runs the 256x256 tile's 4-wave configuration, id 18, when K >= 4096 is a multiple of 64, the LoRA rank is 0 or 32
+ * and the epilogue is alpha / bias / residual only -- same tile grid, same remainder split, sums added in a different order.)
  * Host-only (no launch): lets callers and tests inspect the decision. */
 int ovla_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t K2, int32_t k2_group_n, int64_t workspace_bytes, int32_t* tile,
                    int32_t* full_tiles, int32_t* rem_tiles, int32_t* rem_splits, double* est_seconds);

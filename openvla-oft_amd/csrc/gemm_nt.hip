@@ -1854,6 +1854,12 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     else {   // 256x256 / 128x128 / 64x128 / 128x32 tiles, whichever the hybrid-schedule cost model predicts fastest
       hybrid = true;
       tile = pick_tile(p.M, p.N, T, p.k2_group_n, wsb / 4, nullptr);
+      // The 4-wave config of the 256x256 tile (hand-scheduled K loop: +4 % in the loop, a dearer read-back) where it measured ahead of the 8-wave one
+      // (tools/gemm_w4_probe.py): K >= 4096 in whole K tiles, LoRA rank 0 or 32, the alpha / bias / residual epilogue.  OVLA_GEMM_W4=0 switches it off.
+      static const bool w4_on = []() { const char* e = getenv("OVLA_GEMM_W4"); return !(e && e[0] == '0'); }();
+      if (w4_on && tile == 17 && p.K >= 4096 && (p.K % BK) == 0 && (p.K2 == 0 || p.K2 == 32) && (p.k2_group_n % 256) == 0 && p.fast_addr && p.fast_epi &&
+          p.act == OVLA_ACT_NONE && !a->C_pre && !a->colscale && !a->rowsq_out && !a->rowscale_part && p.split_k <= 1)
+        tile = 18;
     }
   }
   if (a->rope_cos) {
@@ -1903,7 +1909,7 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     case 116: return launch_cfg<256, 256, 4, 2>(p, stream, wsb, true);
     case 17: return launch_cfg<256, 256, 2, 4>(p, stream, wsb, hybrid);   // 2x4 waves (128x64 wave tiles)
     case 117: return launch_cfg<256, 256, 2, 4>(p, stream, wsb, true);
-    case 18: return p.K2 > 0 ? launch_w4<true>(p, stream, wsb, false) : launch_w4<false>(p, stream, wsb, false);   // 4-wave 256x256, register-staged operands, hand-scheduled K loop
+    case 18: return p.K2 > 0 ? launch_w4<true>(p, stream, wsb, hybrid) : launch_w4<false>(p, stream, wsb, hybrid);   // 4-wave 256x256, register-staged operands, hand-scheduled K loop
     case 118: return p.K2 > 0 ? launch_w4<true>(p, stream, wsb, true) : launch_w4<false>(p, stream, wsb, true);
     case 101: return launch_cfg<128, 128, 2, 2>(p, stream, wsb, true);
     case 102: return launch_cfg<64, 128, 1, 4>(p, stream, wsb, true);

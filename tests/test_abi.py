@@ -112,3 +112,42 @@ def test_shipped_code_object_has_no_packed_fp32(libmod, tmp_path):
     # and build.sh compiles every .hip file of the directory with the flag
     sh = (ROOT / "openvla-oft_amd" / "csrc" / "build.sh").read_text()
     assert 'SRCS="$(ls *.hip' in sh and 'NOPK="$SRCS"' in sh
+
+
+def test_w4_gemm_loop_is_what_the_source_wrote(libmod, tmp_path):
+    """The 4-wave 256x256 GEMM's K loop is inline asm with hand-counted `s_waitcnt`s (gemm_nt.hip: gemm_nt_w4_kernel).  That is only sound while the
+    compiler adds nothing of its own between the asm statements: a register copy of an asm load's destination would read it before the wait, a spill would
+    change the vmcnt arithmetic, a v_readfirstlane feeding an asm load's SGPR base needs wait states the compiler cannot insert.  This test disassembles
+    the shipped kernels and checks the loop bodies: per K tile 128 MFMAs, 32 ds_read_b128, 16 ds_write_b128, 16 global_load_dwordx4 -- and NO other vector
+    ALU instruction, no AGPR move, no scratch access, no readfirstlane."""
+    import re
+    import shutil
+
+    objdump = Path("/opt/rocm/lib/llvm/bin/llvm-objdump")
+    if not objdump.exists():
+        pytest.skip("llvm-objdump not in this image")
+    so = tmp_path / "libovla_hip.so"
+    shutil.copy(libmod.LIB_PATH, so)
+    subprocess.run([str(objdump), "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    seen = 0
+    for o in sorted(tmp_path.glob("libovla_hip.so.*gfx950*")):
+        text = subprocess.run([str(objdump), "-d", str(o)], check=True, capture_output=True, text=True).stdout
+        for m in re.finditer(r"<(_ZN\S*gemm_nt_w4_kernel\S*)>:\n(.*?)(?=\n\n|\Z)", text, re.S):
+            ins = [ln.split("//")[0].split("\t")[1].strip() if "\t" in ln else ln.strip() for ln in m.group(2).splitlines() if ln.strip()]
+            ops = [i.split()[0] for i in ins if i and not i.endswith(":")]
+            barriers = [k for k, op in enumerate(ops) if op == "s_barrier"]
+            # the K loop = the stretch between the first and the last s_barrier that is followed by MFMAs (main loop x2 bodies + the odd tail body);
+            # the epilogue's barrier (__syncthreads) comes after the last MFMA
+            last_mfma = max(k for k, op in enumerate(ops) if op.startswith("v_mfma"))
+            body_starts = [k for k in barriers if k < last_mfma]
+            seen += 1
+            assert len(body_starts) == 3, f"{m.group(1)}: {len(body_starts)} K-loop bodies (two unrolled + the odd tail expected)"
+            # a body = from its barrier to its last MFMA (what lies between two bodies -- loop control, the branch to the tail -- is the compiler's)
+            ends = [max(k for k in range(b, nxt) if ops[k].startswith("v_mfma")) for b, nxt in zip(body_starts, body_starts[1:] + [last_mfma + 1])]
+            loop = [op for b, e in zip(body_starts, ends) for op in ops[b:e + 1]]
+            c = lambda pre: sum(1 for op in loop if op.startswith(pre))
+            assert c("v_mfma") == 3 * 128 + 8, (m.group(1), c("v_mfma"))                       # + the last deferred row
+            assert c("ds_read_b128") == 3 * 32 and c("ds_write_b128") == 2 * 16 and c("global_load_dwordx4") == 2 * 16, (c("ds_read_b128"), c("ds_write_b128"), c("global_load_dwordx4"))
+            alien = [op for op in loop if op.startswith(("v_", "scratch_", "buffer_", "flat_")) and not op.startswith("v_mfma")]
+            assert not alien, f"{m.group(1)}: the compiler put {sorted(set(alien))} inside the hand-scheduled K loop"
+    assert seen == 2, f"{seen} gemm_nt_w4_kernel instantiations found in the shipped library (with and without the K-extension expected)"

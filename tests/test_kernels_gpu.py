@@ -122,6 +122,58 @@ def test_gemm_lora_extension(ops, dev, groups, K2, tile):
     close(out, ref.to(BF), what=f"lora k-extension groups={groups} K2={K2}")
 
 
+W4_SHAPES = [(128, 128, 64), (1000, 512, 1024), (300, 520, 192), (515, 1152, 1152), (256, 256, 448), (4864, 4096, 1024), (2500, 2304, 2048)]
+
+
+@pytest.mark.parametrize("M,N,K", W4_SHAPES)
+@pytest.mark.parametrize("tile", [18, 118])
+@pytest.mark.parametrize("variant", ["plain", "lora", "lora3", "bias_res", "gelu_pre", "split2"])
+def test_gemm_w4_config(ops, dev, M, N, K, tile, variant):
+    """The 4-wave 256x256 configuration (tiles 18 / 118 = with the hybrid remainder schedule; hand-scheduled inline-asm K loop, LoRA K-extension as a
+    prologue, read-back epilogues) against torch fp32 on the same bf16 operands: odd and even K-tile counts, edge tiles, every epilogue path, split-K."""
+    torch.manual_seed(M + N + K + len(variant))
+    a, b = rnd(M, K, dev=dev, scale=0.5), rnd(N, K, dev=dev, scale=0.1)
+    ref = a.float() @ b.float().T
+    kw = {}
+    if variant in ("lora", "bias_res", "gelu_pre"):
+        t, lb = rnd(M, 32, dev=dev), rnd(N, 32, dev=dev, scale=0.2)
+        kw.update(a2=t, b2=lb)
+        ref = ref + t.float() @ lb.float().T
+    if variant == "lora3":
+        if N % 768 != 0:
+            pytest.skip("grouped K-extension needs 256-column groups")
+        G, Ng = 3, N // 3
+        t, lb = rnd(M, 32 * G, dev=dev), rnd(N, 32, dev=dev, scale=0.2)
+        kw.update(a2=t, b2=lb, k2_group_n=Ng)
+        for g in range(G):
+            ref[:, g * Ng:(g + 1) * Ng] += t[:, g * 32:(g + 1) * 32].float() @ lb[g * Ng:(g + 1) * Ng].float().T
+    ref = ref.to(BF).float()
+    if variant == "bias_res":
+        bias, res = rnd(N, dev=dev), rnd(M, N, dev=dev)
+        kw.update(bias=bias, residual=res)
+        ref = ((a.float() @ b.float().T + kw["a2"].float() @ kw["b2"].float().T + bias.float()).to(BF).float() + res.float()).to(BF).float()
+    if variant == "gelu_pre":
+        bias, pre = rnd(N, dev=dev), torch.empty(M, N, dtype=BF, device=dev)
+        kw.update(bias=bias, act=1, c_pre=pre)
+        z = (a.float() @ b.float().T + kw["a2"].float() @ kw["b2"].float().T + bias.float()).to(BF)
+        ref = torch.nn.functional.gelu(z.float()).to(BF).float()
+    if variant == "split2":
+        kw.update(split_k=2)
+    out = ops.gemm(a, b, tile=tile, **kw)
+    close(out, ref.to(BF), what=f"w4 {variant} {M}x{N}x{K} tile {tile}")
+    if variant == "gelu_pre":
+        close(kw["c_pre"], z, what="w4 pre-activation")
+
+
+def test_gemm_w4_refuses_what_it_cannot_do(ops, dev):
+    a, b = rnd(256, 72, dev=dev), rnd(256, 72, dev=dev)
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, b, tile=18)                                             # K not a multiple of 64
+    a, b = rnd(256, 128, dev=dev), rnd(256, 128, dev=dev)
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, b, a2=rnd(256, 16, dev=dev), b2=rnd(256, 16, dev=dev), tile=18)   # K-extension other than 32
+
+
 @pytest.mark.parametrize("tile", [0, 10, 5])
 @pytest.mark.parametrize("split_k", [2, 8])
 def test_gemm_split_k(ops, dev, split_k, tile):
@@ -540,6 +592,12 @@ def test_image_prep_bit_exact_vs_oracle(ops, dev, crop, hw):
     assert torch.equal(got.cpu(), ref), f"{(got.cpu() != ref).sum().item()} of {ref.numel()} values differ"
 
 
+def _resolved_tile(ops, M, N, K, tile, K2=32):
+    """tile = 0 resolves per call (the 4-wave 256x256 config takes the plain / bias / residual epilogues only): a bit-for-bit comparison of a fused
+    epilogue with its unfused sequence pins both GEMMs to the configuration the planner names."""
+    return {17: 117, 1: 101, 2: 102, 5: 105}[ops.gemm_plan(M, N, K, K2)[0]] if tile == 0 and M > 64 and N > 128 else tile
+
+
 @pytest.mark.parametrize("M,N,K,tile", [(4864, 1024, 4096, 0), (1000, 512, 256, 1), (300, 264, 1088, 101), (522, 1024, 4096, 0)])
 @pytest.mark.parametrize("act", [1, 2, 3])
 def test_gemm_backward_epilogue_act(ops, dev, M, N, K, tile, act):
@@ -548,6 +606,7 @@ def test_gemm_backward_epilogue_act(ops, dev, M, N, K, tile, act):
     a, b = rnd(M, K, dev=dev, scale=0.3), rnd(N, K, dev=dev, scale=0.1)
     t, lb = rnd(M, 32, dev=dev), rnd(N, 32, dev=dev, scale=0.2)
     z = rnd(M, N, dev=dev)
+    tile = _resolved_tile(ops, M, N, K, tile)
     dh = ops.gemm(a, b, a2=t, b2=lb, tile=tile)
     ref = ops.act_bwd(z, dh, act)
     got = ops.gemm(a, b, a2=t, b2=lb, tile=tile, dact=("act", z, act))
@@ -561,6 +620,7 @@ def test_gemm_backward_epilogue_swiglu(ops, dev, M, F, K, tile):
     a, b = rnd(M, K, dev=dev, scale=0.3), rnd(F, K, dev=dev, scale=0.1)
     t, lb = rnd(M, 32, dev=dev), rnd(F, 32, dev=dev, scale=0.2)
     gu = rnd(M, 2 * F, dev=dev)
+    tile = _resolved_tile(ops, M, F, K, tile)
     dh = ops.gemm(a, b, a2=t, b2=lb, tile=tile)
     ref = ops.swiglu_bwd(gu, dh)
     got = ops.gemm(a, b, a2=t, b2=lb, tile=tile, dact=("swiglu", gu))
@@ -589,7 +649,8 @@ def test_attn_bwd_fused_inverse_rope(ops, dev, hd, S, causal):
 
 
 @pytest.mark.parametrize("M,S,tile", [(4864, 608, 0), (4864, 608, 116), (4864, 608, 117), (4864, 608, 17), (512, 128, 17), (608, 608, 0), (608, 608, 17),
-                                      (1216, 304, 16), (700, 100, 1), (520, 130, 2), (608, 608, 1), (608, 608, 101), (1000, 250, 101), (4864, 608, 101)])
+                                      (1216, 304, 16), (700, 100, 1), (520, 130, 2), (608, 608, 1), (608, 608, 101), (1000, 250, 101), (4864, 608, 101),
+                                      (4864, 608, 118), (4864, 608, 18), (700, 100, 18), (1216, 304, 118)])
 def test_gemm_rope_epilogue(ops, dev, M, S, tile):
     """RoPE in the q|k|v projection's epilogue (fused in the 256x256 configs: 2x4 waves = the default layout, in its unrolled read-back with
     the partner-column wave map, and 4x2 waves; since round 3 also in the 128x128 config -- one head per column tile, any M: the batch-1 chunk's
