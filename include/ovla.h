@@ -118,6 +118,9 @@ typedef struct {
  * Host-only (no launch): lets callers and tests inspect the decision. */
 int ovla_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t K2, int32_t k2_group_n, int64_t workspace_bytes, int32_t* tile,
                    int32_t* full_tiles, int32_t* rem_tiles, int32_t* rem_splits, double* est_seconds);
+/* The tile configuration ovla_gemm_bf16 would run for exactly these arguments (same checks, same decision code, no launch): what profilers and
+ * bench.py use to name the kernel instance of a launch.  6 = the single-launch skinny kernel. */
+int ovla_gemm_resolved_tile(const ovla_gemm_args* a, int32_t* tile);
 int64_t ovla_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
 int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream);
 

@@ -1747,6 +1747,17 @@ extern "C" int64_t ovla_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split
   return split_k > 1 ? (int64_t)split_k * M * N * 4 : 0;
 }
 
+static thread_local int32_t* g_resolve_only = nullptr;   // ovla_gemm_resolved_tile: run the argument checks and the schedule decision, launch nothing
+
+extern "C" int ovla_gemm_resolved_tile(const ovla_gemm_args* a, int32_t* tile) {
+  OVLA_REQUIRE(tile != nullptr, "ovla_gemm_resolved_tile: null output");
+  *tile = -1;
+  g_resolve_only = tile;
+  const int rc = ovla_gemm_bf16(a, nullptr);
+  g_resolve_only = nullptr;
+  return rc;
+}
+
 extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   OVLA_REQUIRE(a != nullptr, "ovla_gemm_bf16: null args");
@@ -1844,6 +1855,7 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     static const bool skinny_on = []() { const char* e = getenv("OVLA_SKINNY"); return !(e && e[0] == '0'); }();   // A/B switch
     if (skinny_on && p.N == 32 && p.a_group_n == 0 && p.K <= 3072 && p.M >= 512 && p.K2 == 0 && p.split_k <= 1 && !a->bias && !a->C_pre && !a->colscale &&
         !a->residual && !a->film_gamma && !a->dact_src && !a->rope_cos && a->act == OVLA_ACT_NONE) {
+      if (g_resolve_only) { *g_resolve_only = 6; return OVLA_OK; }
       hipLaunchKernelGGL(gemm_skinny_kernel<2>, dim3((unsigned)cdiv(p.M, 32)), dim3(256), 0, stream, p);
       OVLA_CHECK_LAUNCH("ovla_gemm_bf16(skinny)");
       return OVLA_OK;
@@ -1862,6 +1874,7 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
         tile = 18;
     }
   }
+  if (g_resolve_only) { *g_resolve_only = tile; return OVLA_OK; }
   if (a->rope_cos) {
     // fused only where one wave slab is one head (256x256 tile, 4x2 waves) and the epilogue runs in-kernel or in the hybrid reduce;
     // every other schedule computes the plain projection and rotates it with one ovla_rope launch (same arithmetic)

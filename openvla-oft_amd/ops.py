@@ -154,26 +154,18 @@ def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=Non
     e0 = _prof_begin()
     _lib.call("ovla_gemm_bf16", g, _stream())
     if e0 is not None:
-        _prof_end(e0, _gemm_family(M, N, K, g.K2, k2_group_n, a_group_n, split_k, tile), 2.0 * M * N * (K + (b2.shape[1] if b2 is not None else 0)))
+        _prof_end(e0, _gemm_family(g), 2.0 * M * N * (K + (b2.shape[1] if b2 is not None else 0)))
     return out
 
 
-def _gemm_family(M, N, K, K2, k2_group_n, a_group_n, split_k, tile):
-    """Profiling only: which kernel instance `ovla_gemm_bf16` runs for this call ("gemm_nt_t17" = gemm_nt_kernel<256,256,2,4>, ...),
-    from the same host-side decision the library makes (ovla_gemm_plan) -- so bench.py can report the dominant instance by itself."""
+def _gemm_family(g):
+    """Profiling only: which kernel instance `ovla_gemm_bf16` runs for these arguments ("gemm_nt_t17" = gemm_nt_kernel<256,256,2,4>, "gemm_nt_t18" = the
+    4-wave gemm_nt_w4_kernel, ...), from the library's own decision code (ovla_gemm_resolved_tile) -- so bench.py can report the dominant instance by itself."""
     import ctypes
 
-    if tile:
-        return f"gemm_nt_t{tile % 100 if tile >= 100 else tile}"
-    if N <= 32 or a_group_n == 32:
-        return "gemm_nt_t5"
-    if a_group_n:
-        return "gemm_nt_t1"
-    if M <= 64 or N <= 128:
-        return "gemm_nt_t2"
     t = ctypes.c_int32()
-    _lib.check(_lib.lib().ovla_gemm_plan(M, N, K, K2, k2_group_n, _WS_BYTES, ctypes.byref(t), None, None, None, None), "ovla_gemm_plan")
-    return f"gemm_nt_t{t.value}"
+    _lib.check(_lib.lib().ovla_gemm_resolved_tile(ctypes.byref(g), ctypes.byref(t)), "ovla_gemm_resolved_tile")
+    return f"gemm_nt_t{t.value % 100 if t.value >= 100 else t.value}"
 
 
 def gemm_tn(x, y, *, out=None, alpha=1.0, accumulate=True, out_dtype=torch.float32):

@@ -30,7 +30,7 @@ def main():
     tag = sys.argv[sys.argv.index("--round") + 1] if "--round" in sys.argv else "r02"
     fetch = per_kernel(d / "FETCH_SIZE" / "pmc_counter_collection.csv", "FETCH_SIZE")
     write = per_kernel(d / "WRITE_SIZE" / "pmc_counter_collection.csv", "WRITE_SIZE")
-    gemm = [k for k in fetch if "gemm_nt_kernel" in k]
+    gemm = [k for k in fetch if "gemm_nt_kernel" in k or "gemm_nt_w4_kernel" in k]
     assert gemm, "no gemm_nt_kernel launch in the trace"
     dom = max(gemm, key=lambda k: sum(fetch[k]))
     red = [k for k in fetch if "gemm_hybrid_reduce" in k or "gemm_splitk_reduce" in k]
