@@ -860,7 +860,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   uint32_t rb[2][2] = {{rb0, rb0 ^ 64}, {rb0 + TILE_BYTES, (rb0 ^ 64) + TILE_BYTES}};
 
   u32x4 g[16];
-  bf16x8_bits b0[NT], b1[NT], a_cur, a_nxt;
+  bf16x8_bits b0[NT], b1[NT];
   bf16x8_bits a_def = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int j = 0; j < NT; ++j) b1[j] = a_def;
@@ -926,46 +926,57 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   // times, so `vmcnt(15)` is exactly "the load issued 16 loads ago has landed".
   // (STAGE = false: the odd last tile, after which nothing is staged any more.  A staging load whose result is never used would be a DEAD asm output: the
   // compiler then hands its destination registers to the next live value while the load is still in flight -- seen in the listing, half a K tile lost.)
+  // Inside a row the non-MFMA instructions sit BETWEEN the MFMAs (one after each of the first four), not in a block between two rows: the wave issues in
+  // order, so a block of six other instructions after a row's eighth MFMA let the matrix pipe run dry for ~10 of every 138 cycles (measured 1.38 us per K tile
+  // against 1.24 at the loop's clock ceiling).  Fragment reads run TWO rows ahead (three A fragments live).  LDS operations in program order --
+  //   top: b0[0..7], a(0), a(1), [w15]      row r: a(r + 2) (r <= 13), b1[r] (r <= 7), [w r]      ([..] = with staging)
+  // -- give the `lgkmcnt` a row needs before its first MFMA: everything NEWER than the youngest fragment it uses may stay in flight.
   auto body = [&](const int t, auto par_tag, auto stage_tag) {
     constexpr int PAR = decltype(par_tag)::value;
     constexpr bool STAGE = decltype(stage_tag)::value;
     const char* gA = tile_base(p.A, clampt(t + 2));
     const char* gB = tile_base(p.B, clampt(t + 2));
+    bf16x8_bits af[3];
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier");   // tile t is in LDS (everyone's ds_writes), nobody reads the other buffer any more
     static_for<NT>([&](auto j_tag) { constexpr int j = decltype(j_tag)::value; b0[j] = w4_ds_read<j * 2048>(rb[PAR][0]); });
-    a_cur = w4_ds_read<0>(ra[PAR][0]);
-    if constexpr (STAGE) {
-      asm volatile("s_waitcnt vmcnt(15)");
-      w4_ds_write<7 * 1024 + BM * 128>(wr[PAR ^ 1][1], g[15]);
-      g[15] = w4_gload(offB[7], gB);
-    }
+    af[0] = w4_ds_read<0>(ra[PAR][0]);
+    af[1] = w4_ds_read<2048>(ra[PAR][0]);
     asm volatile("s_setprio 1");
-    static_for<NT>([&](auto j_tag) { constexpr int j = decltype(j_tag)::value; acc[MT - 1][j] = w4_mfma(acc[MT - 1][j], b1[j], a_def); });   // deferred row of tile t - 1
+    // deferred row of tile t - 1, with the top's staging piece between its MFMAs
+    acc[MT - 1][0] = w4_mfma(acc[MT - 1][0], b1[0], a_def);
+    if constexpr (STAGE) { asm volatile("s_waitcnt vmcnt(15)"); w4_ds_write<7 * 1024 + BM * 128>(wr[PAR ^ 1][1], g[15]); }
+    acc[MT - 1][1] = w4_mfma(acc[MT - 1][1], b1[1], a_def);
+    if constexpr (STAGE) g[15] = w4_gload(offB[7], gB);
+    static_for<NT - 2>([&](auto j_tag) { constexpr int j = decltype(j_tag)::value + 2; acc[MT - 1][j] = w4_mfma(acc[MT - 1][j], b1[j], a_def); });
     static_for<2 * MT - 1>([&](auto r_tag) {
       constexpr int r = decltype(r_tag)::value;
       constexpr int sub = r / MT, i = r % MT;
-      constexpr int rn = r + 1, subn = rn / MT, in_ = rn % MT;
-      a_nxt = w4_ds_read<in_ * 2048>(ra[PAR][subn]);
+      // youngest fragment row r uses: a(r) -- issued two rows earlier (a(0), a(1): at the top) -- except row MT, which also needs b1[MT - 1] (row MT - 1's
+      // last read).  Newer LDS operations, with / without staging:
+      //   r = 0: a(1), [w15]                      -> 2 / 1        r = 1: [w15], a(2), b1[0], [w0]                 -> 4 / 2
+      //   2 <= r <= MT - 1 and r = MT + 1: b1, [w], a, b1, [w]   (r = MT + 1: b1[MT-1], [w], a, [w])   -> 5 / 3 (4 / 2)
+      //   r = MT: [w(MT-1)]                       -> 1 / 0        r >= MT + 2: [w], a(r + 1), [w]                 -> 3 / 1
+      constexpr int newer = r == 0 ? (STAGE ? 2 : 1) : r == 1 ? (STAGE ? 4 : 2) : r < MT ? (STAGE ? 5 : 3) : r == MT ? (STAGE ? 1 : 0) : r == MT + 1 ? (STAGE ? 4 : 2) : (STAGE ? 3 : 1);
+      asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(newer));
+      auto mf = [&](auto j_tag) {
+        constexpr int j = decltype(j_tag)::value;
+        if constexpr (sub == 0) acc[i][j] = w4_mfma(acc[i][j], b0[j], af[r % 3]);
+        else acc[i][j] = w4_mfma(acc[i][j], b1[j], af[r % 3]);
+      };
+      mf(std::integral_constant<int, 0>{});
+      if constexpr (r + 2 <= 2 * MT - 1) af[(r + 2) % 3] = w4_ds_read<((r + 2) % MT) * 2048>(ra[PAR][(r + 2) / MT]);
+      mf(std::integral_constant<int, 1>{});
       if constexpr (sub == 0) b1[i] = w4_ds_read<i * 2048>(rb[PAR][1]);
+      mf(std::integral_constant<int, 2>{});
+      if constexpr (STAGE) { asm volatile("s_waitcnt vmcnt(15)"); w4_ds_write<(r & 7) * 1024 + (r < 8 ? 0 : BM * 128)>(wr[PAR ^ 1][r & 1], g[r]); }
+      mf(std::integral_constant<int, 3>{});
       if constexpr (STAGE) {
-        asm volatile("s_waitcnt vmcnt(15)");
-        w4_ds_write<(r & 7) * 1024 + (r < 8 ? 0 : BM * 128)>(wr[PAR ^ 1][r & 1], g[r]);
         if constexpr (r < 8) g[r] = w4_gload(offA[r], gA);
         else g[r] = w4_gload(offB[r - 8], gB);
       }
-      // a(r) is the FIRST LDS operation of row r - 1 (a(0): of the top, before the top's ds_write); everything issued after it may stay in flight:
-      // row r - 1's [b1 read] and ds_write, this row's a(r + 1), [b1 read] and ds_write.  (The b fragments a row uses are older than its a fragment.)
-      // (row MT, the first of the second k substep, also needs b1[MT - 1], which row MT - 1 issued right AFTER a(MT))
-      constexpr int newer = (r == 0 ? (STAGE ? 4 : 2) : sub == 0 ? (STAGE ? 5 : 3) : (STAGE ? 3 : 1));
-      asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(newer));
-      static_for<NT>([&](auto j_tag) {
-        constexpr int j = decltype(j_tag)::value;
-        if constexpr (sub == 0) acc[i][j] = w4_mfma(acc[i][j], b0[j], a_cur);
-        else acc[i][j] = w4_mfma(acc[i][j], b1[j], a_cur);
-      });
-      a_cur = a_nxt;
+      static_for<NT - 4>([&](auto j_tag) { mf(std::integral_constant<int, decltype(j_tag)::value + 4>{}); });
     });
-    a_def = a_cur;
+    a_def = af[(2 * MT - 1) % 3];
     asm volatile("s_setprio 0");
   };
   int t = t_begin;
@@ -1866,11 +1877,11 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     else {   // 256x256 / 128x128 / 64x128 / 128x32 tiles, whichever the hybrid-schedule cost model predicts fastest
       hybrid = true;
       tile = pick_tile(p.M, p.N, T, p.k2_group_n, wsb / 4, nullptr);
-      // The 4-wave config of the 256x256 tile (hand-scheduled K loop: +4 % in the loop, a dearer read-back) where it measured ahead of the 8-wave one
-      // (tools/gemm_w4_probe.py): K >= 4096 in whole K tiles, LoRA rank 0 or 32, the alpha / bias / residual epilogue.  OVLA_GEMM_W4=0 switches it off.
+      // The 4-wave config of the 256x256 tile (hand-scheduled K loop) where it measured ahead of the 8-wave one (tools/gemm_w4_probe.py: +4...9 % per launch on
+      // the decoder shapes): K >= 4096 in whole K tiles, LoRA rank 0 or 32, the alpha / bias / residual or the RoPE epilogue.  OVLA_GEMM_W4=0 switches it off.
       static const bool w4_on = []() { const char* e = getenv("OVLA_GEMM_W4"); return !(e && e[0] == '0'); }();
-      if (w4_on && tile == 17 && p.K >= 4096 && (p.K % BK) == 0 && (p.K2 == 0 || p.K2 == 32) && (p.k2_group_n % 256) == 0 && p.fast_addr && p.fast_epi &&
-          p.act == OVLA_ACT_NONE && !a->C_pre && !a->colscale && !a->rowsq_out && !a->rowscale_part && p.split_k <= 1)
+      if (w4_on && tile == 17 && p.K >= 4096 && (p.K % BK) == 0 && (p.K2 == 0 || p.K2 == 32) && (p.k2_group_n % 256) == 0 && p.fast_addr &&
+          (p.fast_epi || (a->rope_cos && rope_plain)) && p.act == OVLA_ACT_NONE && !a->C_pre && !a->colscale && !a->rowsq_out && !a->rowscale_part && p.split_k <= 1)
         tile = 18;
     }
   }
