@@ -785,7 +785,7 @@ template <int OFF> OVLA_DEV void w4_ds_write(uint32_t addr, u32x4 src) { asm vol
 OVLA_DEV f32x4 w4_pin(f32x4 v) { asm volatile("" : "+a"(v)); return v; }
 OVLA_DEV void w4_keep(u32x4 v) { asm volatile("" : : "v"(v)); }
 OVLA_DEV u32x4 w4_gload(uint32_t voff, const char* sbase) { u32x4 dst; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase)); return dst; }
-template <bool KEXT>
+template <bool KEXT, int ABL = 0>   // ABL: timing-only ablations (OVLA_GEMM_ABLATE builds), bits: 1 = no staging after the prologue, 2 = no fragment reads, 4 = no lgkmcnt waits in the rows, 8 = no vmcnt waits in the rows
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, WTM = 128, WTN = 128, MT = 8, NT = 8;
   constexpr int TILE_BYTES = (BM + BN) * BK * 2;   // 65536
@@ -931,23 +931,28 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   // against 1.24 at the loop's clock ceiling).  Fragment reads run TWO rows ahead (three A fragments live).  LDS operations in program order --
   //   top: b0[0..7], a(0), a(1), [w15]      row r: a(r + 2) (r <= 13), b1[r] (r <= 7), [w r]      ([..] = with staging)
   // -- give the `lgkmcnt` a row needs before its first MFMA: everything NEWER than the youngest fragment it uses may stay in flight.
-  auto body = [&](const int t, auto par_tag, auto stage_tag) {
+  auto body = [&](const int t, auto par_tag, auto stage_tag, auto shift_tag) {
     constexpr int PAR = decltype(par_tag)::value;
-    constexpr bool STAGE = decltype(stage_tag)::value;
+    constexpr int SHIFT = decltype(shift_tag)::value;   // = the wave's index: its memory instructions sit SHIFT MFMA gaps later in every row than wave 0's (below)
+    constexpr bool STAGE = decltype(stage_tag)::value && !(ABL & 1);
+    constexpr bool FRAG = !(ABL & 2);
     const char* gA = tile_base(p.A, clampt(t + 2));
     const char* gB = tile_base(p.B, clampt(t + 2));
     bf16x8_bits af[3];
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier");   // tile t is in LDS (everyone's ds_writes), nobody reads the other buffer any more
+    if constexpr (FRAG) {
     static_for<NT>([&](auto j_tag) { constexpr int j = decltype(j_tag)::value; b0[j] = w4_ds_read<j * 2048>(rb[PAR][0]); });
     af[0] = w4_ds_read<0>(ra[PAR][0]);
     af[1] = w4_ds_read<2048>(ra[PAR][0]);
+    } else { af[0] = af[1] = af[2] = a_def; }
     asm volatile("s_setprio 1");
     // deferred row of tile t - 1, with the top's staging piece between its MFMAs
-    acc[MT - 1][0] = w4_mfma(acc[MT - 1][0], b1[0], a_def);
-    if constexpr (STAGE) { asm volatile("s_waitcnt vmcnt(15)"); w4_ds_write<7 * 1024 + BM * 128>(wr[PAR ^ 1][1], g[15]); }
-    acc[MT - 1][1] = w4_mfma(acc[MT - 1][1], b1[1], a_def);
-    if constexpr (STAGE) g[15] = w4_gload(offB[7], gB);
-    static_for<NT - 2>([&](auto j_tag) { constexpr int j = decltype(j_tag)::value + 2; acc[MT - 1][j] = w4_mfma(acc[MT - 1][j], b1[j], a_def); });
+    static_for<NT>([&](auto j_tag) {
+      constexpr int j = decltype(j_tag)::value;
+      acc[MT - 1][j] = w4_mfma(acc[MT - 1][j], b1[j], a_def);
+      if constexpr (STAGE && j == SHIFT) { asm volatile("s_waitcnt vmcnt(15)"); w4_ds_write<7 * 1024 + BM * 128>(wr[PAR ^ 1][1], g[15]); }
+      if constexpr (STAGE && j == SHIFT + 1) g[15] = w4_gload(offB[7], gB);
+    });
     static_for<2 * MT - 1>([&](auto r_tag) {
       constexpr int r = decltype(r_tag)::value;
       constexpr int sub = r / MT, i = r % MT;
@@ -957,35 +962,42 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
       //   2 <= r <= MT - 1 and r = MT + 1: b1, [w], a, b1, [w]   (r = MT + 1: b1[MT-1], [w], a, [w])   -> 5 / 3 (4 / 2)
       //   r = MT: [w(MT-1)]                       -> 1 / 0        r >= MT + 2: [w], a(r + 1), [w]                 -> 3 / 1
       constexpr int newer = r == 0 ? (STAGE ? 2 : 1) : r == 1 ? (STAGE ? 4 : 2) : r < MT ? (STAGE ? 5 : 3) : r == MT ? (STAGE ? 1 : 0) : r == MT + 1 ? (STAGE ? 4 : 2) : (STAGE ? 3 : 1);
-      asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(newer));
+      if constexpr (FRAG && !(ABL & 4)) asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(newer));
       auto mf = [&](auto j_tag) {
         constexpr int j = decltype(j_tag)::value;
         if constexpr (sub == 0) acc[i][j] = w4_mfma(acc[i][j], b0[j], af[r % 3]);
         else acc[i][j] = w4_mfma(acc[i][j], b1[j], af[r % 3]);
       };
-      mf(std::integral_constant<int, 0>{});
-      if constexpr (r + 2 <= 2 * MT - 1) af[(r + 2) % 3] = w4_ds_read<((r + 2) % MT) * 2048>(ra[PAR][(r + 2) / MT]);
-      mf(std::integral_constant<int, 1>{});
-      if constexpr (sub == 0) b1[i] = w4_ds_read<i * 2048>(rb[PAR][1]);
-      mf(std::integral_constant<int, 2>{});
-      if constexpr (STAGE) { asm volatile("s_waitcnt vmcnt(15)"); w4_ds_write<(r & 7) * 1024 + (r < 8 ? 0 : BM * 128)>(wr[PAR ^ 1][r & 1], g[r]); }
-      mf(std::integral_constant<int, 3>{});
-      if constexpr (STAGE) {
-        if constexpr (r < 8) g[r] = w4_gload(offA[r], gA);
-        else g[r] = w4_gload(offB[r - 8], gB);
-      }
-      static_for<NT - 4>([&](auto j_tag) { mf(std::integral_constant<int, decltype(j_tag)::value + 4>{}); });
+      // one memory instruction per MFMA gap: a-fragment read, b-fragment read, vmcnt, ds_write, global load after MFMAs SHIFT .. SHIFT + 4
+      static_for<NT>([&](auto j_tag) {
+        constexpr int j = decltype(j_tag)::value, k = j - SHIFT;
+        mf(j_tag);
+        if constexpr (k == 0 && FRAG && r + 2 <= 2 * MT - 1) af[(r + 2) % 3] = w4_ds_read<((r + 2) % MT) * 2048>(ra[PAR][(r + 2) / MT]);
+        if constexpr (k == 1 && FRAG && sub == 0) b1[i] = w4_ds_read<i * 2048>(rb[PAR][1]);
+        if constexpr (k == 2 && STAGE && !(ABL & 8)) asm volatile("s_waitcnt vmcnt(15)");
+        if constexpr (k == 3 && STAGE) w4_ds_write<(r & 7) * 1024 + (r < 8 ? 0 : BM * 128)>(wr[PAR ^ 1][r & 1], g[r]);
+        if constexpr (k == 4 && STAGE) {
+          if constexpr (r < 8) g[r] = w4_gload(offA[r], gA);
+          else g[r] = w4_gload(offB[r - 8], gB);
+        }
+      });
     });
     a_def = af[(2 * MT - 1) % 3];
     asm volatile("s_setprio 0");
   };
-  int t = t_begin;
   OVLA_STAMP(2);
-  for (; t + 1 < t_end; t += 2) {
-    body(t, std::integral_constant<int, 0>{}, std::true_type{});
-    body(t + 1, std::integral_constant<int, 1>{}, std::true_type{});
-  }
-  if (t < t_end) body(t, std::integral_constant<int, 0>{}, std::false_type{});
+  auto k_loop = [&](auto shift_tag) {
+    int t = t_begin;
+    for (; t + 1 < t_end; t += 2) {
+      body(t, std::integral_constant<int, 0>{}, std::true_type{}, shift_tag);
+      body(t + 1, std::integral_constant<int, 1>{}, std::true_type{}, shift_tag);
+    }
+    if (t < t_end) body(t, std::integral_constant<int, 0>{}, std::false_type{}, shift_tag);
+  };
+  // (One loop for all four waves.  Staggering them was tried both ways and dropped: four code variants with the memory instructions SHIFT gaps later, picked
+  // by `wave` -- a four-way branch around asm that updates 64 tied accumulators makes the compiler merge them through AGPR moves and scratch inside the loops,
+  // 140 moves per K tile -- and a time skew of w x 8..96 cycles after the barrier, which only added its own length to every K tile.)
+  k_loop(std::integral_constant<int, 0>{});
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   static_for<16>([&](auto q_tag) { w4_keep(g[decltype(q_tag)::value]); });   // the staging registers stay allocated until their last loads have landed
   static_for<NT>([&](auto j_tag) { constexpr int j = decltype(j_tag)::value; acc[MT - 1][j] = w4_mfma(acc[MT - 1][j], b1[j], a_def); });
@@ -1701,7 +1713,7 @@ int launch_pipe(GemmParams& p, hipStream_t stream) {
   return OVLA_OK;
 }
 
-template <bool KEXT>
+template <bool KEXT, int ABL = 0>
 int launch_w4(GemmParams& p, hipStream_t stream, int64_t ws_bytes, bool hybrid) {
   if (p.K % BK != 0 || p.K2 != (KEXT ? 32 : 0) || !p.fast_addr || p.a_group_n > 0 || p.rowsq_out || p.rowscale_part || (p.k2_group_n > 0 && (p.k2_group_n % 256) != 0)) {
     ovla_set_error("ovla_gemm_bf16: the 4-wave 256x256 config needs K %% 64 == 0, a K-extension of 0 or 32 and no block-diagonal / RMSNorm-fold mode");
@@ -1711,7 +1723,7 @@ int launch_w4(GemmParams& p, hipStream_t stream, int64_t ws_bytes, bool hybrid) 
   p.tiles_n = cdiv(p.N, 256);
   const int splits = p.split_k > 1 ? p.split_k : 1;
   const size_t lds = (size_t)2 * 512 * BK * sizeof(bf16_bits);
-  auto kern = gemm_nt_w4_kernel<KEXT>;
+  auto kern = gemm_nt_w4_kernel<KEXT, ABL>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1935,6 +1947,14 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     case 117: return launch_cfg<256, 256, 2, 4>(p, stream, wsb, true);
     case 18: return p.K2 > 0 ? launch_w4<true>(p, stream, wsb, hybrid) : launch_w4<false>(p, stream, wsb, hybrid);   // 4-wave 256x256, register-staged operands, hand-scheduled K loop
     case 118: return p.K2 > 0 ? launch_w4<true>(p, stream, wsb, true) : launch_w4<false>(p, stream, wsb, true);
+#ifdef OVLA_GEMM_ABLATE
+    case 218: return launch_w4<false, 1>(p, stream, wsb, false);
+    case 318: return launch_w4<false, 2>(p, stream, wsb, false);
+    case 418: return launch_w4<false, 3>(p, stream, wsb, false);
+    case 518: return launch_w4<false, 4>(p, stream, wsb, false);    // no lgkmcnt waits in the rows (wrong results, timing only)
+    case 618: return launch_w4<false, 8>(p, stream, wsb, false);    // no vmcnt waits in the rows
+    case 718: return launch_w4<false, 12>(p, stream, wsb, false);   // neither
+#endif
     case 101: return launch_cfg<128, 128, 2, 2>(p, stream, wsb, true);
     case 102: return launch_cfg<64, 128, 1, 4>(p, stream, wsb, true);
     case 105: return launch_cfg<128, 32, 4, 1>(p, stream, wsb, true);
