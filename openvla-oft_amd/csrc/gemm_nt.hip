@@ -785,7 +785,7 @@ template <int OFF> OVLA_DEV void w4_ds_write(uint32_t addr, u32x4 src) { asm vol
 OVLA_DEV f32x4 w4_pin(f32x4 v) { asm volatile("" : "+a"(v)); return v; }
 OVLA_DEV void w4_keep(u32x4 v) { asm volatile("" : : "v"(v)); }
 OVLA_DEV u32x4 w4_gload(uint32_t voff, const char* sbase) { u32x4 dst; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase)); return dst; }
-template <bool KEXT, int ABL = 0>   // ABL: timing-only ablations (OVLA_GEMM_ABLATE builds), bits: 1 = no staging after the prologue, 2 = no fragment reads, 4 = no lgkmcnt waits in the rows, 8 = no vmcnt waits in the rows
+template <int KEXT, int ABL = 0>   // KEXT: 32-wide k-steps of the LoRA K-extension (0 .. 3);  ABL: timing-only ablations (OVLA_GEMM_ABLATE builds), bits: 1 = no staging after the prologue, 2 = no fragment reads, 4 = no lgkmcnt waits in the rows, 8 = no vmcnt waits in the rows
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 256, WTM = 128, WTN = 128, MT = 8, NT = 8;
   constexpr int TILE_BYTES = (BM + BN) * BK * 2;   // 65536
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   }
 
   f32x4 acc[MT][NT];
-  if constexpr (!KEXT)   // (with a K-extension its MFMAs are the first to touch every accumulator and take the constant 0 as their C operand)
+  if constexpr (KEXT == 0)   // (with a K-extension its MFMAs are the first to touch every accumulator and take the constant 0 as their C operand)
     static_for<MT * NT>([&](auto e_tag) { constexpr int e = decltype(e_tag)::value; acc[e / NT][e % NT] = w4_pin(f32x4{0.f, 0.f, 0.f, 0.f}); });   // pinned: left to itself the compiler keeps the zeros as constants and merges them into the loop through scratch
 
   // staging: piece i of this wave = rows (wave * 8 + i) * 8 .. + 7 of the A (i < 8) / B (i >= 8) tile; lane -> row + (lane >> 3), 16-byte chunk lane & 7
@@ -881,15 +881,24 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   // while that tile is on its way.  (4) Tile t_begin + 1 into the staging registers, in the loop's order.  The compiler counts the vector memory operations
   // it knows (1, 2) when it waits for (1) before (3); the asm loads of (4) are invisible to it, so none of them may be issued before (3).
   OVLA_STAMP(1);
-  bf16x8_bits a2f[KEXT ? MT : 1], b2f[KEXT ? NT : 1];
-  if constexpr (KEXT) {   // K2 == 32 (host-checked).  Straight-line code: a branch around asm that updates 64 accumulators makes the compiler merge them through scratch
+  // (K2 = 32 KEXT, host-checked.  Straight-line code: a branch around asm that updates 64 accumulators makes the compiler merge them through scratch.  Two
+  // fragment sets: steps 0 and 1 are requested up front, step 2 into set 0 once step 0's MFMAs have read it.)
+  bf16x8_bits a2f[KEXT > 1 ? 2 : 1][KEXT ? MT : 1], b2f[KEXT > 1 ? 2 : 1][KEXT ? NT : 1];
+  const bf16_bits* a2p = nullptr;
+  const bf16_bits* b2p = nullptr;
+  auto kext_load = [&](auto set_tag, int ks) {
+    constexpr int S = decltype(set_tag)::value;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { int m = m0 + arow + i * 16; m = m < p.M - 1 ? m : p.M - 1; a2f[S][i] = *reinterpret_cast<const bf16x8_bits*>(a2p + (int64_t)m * p.lda2 + ks * 32); }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { int n = n0 + brow + j * 16; n = n < p.N - 1 ? n : p.N - 1; b2f[S][j] = *reinterpret_cast<const bf16x8_bits*>(b2p + (int64_t)n * p.ldb2 + ks * 32); }
+  };
+  if constexpr (KEXT > 0) {
     const int a2_col0 = p.k2_group_n > 0 ? (n0 / p.k2_group_n) * p.K2 : 0;
-    const bf16_bits* a2p = p.A2 + a2_col0 + 8 * cq;
-    const bf16_bits* b2p = p.B2 + 8 * cq;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) { int m = m0 + arow + i * 16; m = m < p.M - 1 ? m : p.M - 1; a2f[i] = *reinterpret_cast<const bf16x8_bits*>(a2p + (int64_t)m * p.lda2); }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) { int n = n0 + brow + j * 16; n = n < p.N - 1 ? n : p.N - 1; b2f[j] = *reinterpret_cast<const bf16x8_bits*>(b2p + (int64_t)n * p.ldb2); }
+    a2p = p.A2 + a2_col0 + 8 * cq;
+    b2p = p.B2 + 8 * cq;
+    kext_load(std::integral_constant<int, 0>{}, 0);
+    if constexpr (KEXT > 1) kext_load(std::integral_constant<int, 1>{}, 1);
   }
   {
     const char* gA = tile_base(p.A, clampt(t_begin));
@@ -904,12 +913,25 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
                                        (__attribute__((address_space(3))) void*)(smem_raw + BM * 128 + (wave * 8 + i) * 1024), 16, 0, 0);
     }
   }
-  if constexpr (KEXT) {
-    if (t_begin != 0) {   // a later K part of a split tile: the extension belongs to the first part only
+  if constexpr (KEXT > 0) {
+    const bool mine = t_begin == 0;   // a later K part of a split tile: the extension belongs to the first part only (zero fragments, same instruction stream)
+    static_for<KEXT>([&](auto s_tag) {
+      constexpr int st = decltype(s_tag)::value, S = st & 1;
+      if (!mine) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a2f[i] = bf16x8_bits{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-    static_for<MT * NT>([&](auto e_tag) { constexpr int i = decltype(e_tag)::value / NT, j = decltype(e_tag)::value % NT; acc[i][j] = w4_mfma0(b2f[j], a2f[i]); });
+        for (int i = 0; i < MT; ++i) a2f[S][i] = bf16x8_bits{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+      // The compiler may have written a fragment register with a VALU instruction right here (the zeroing above, or a v_mov restoring a register it borrowed
+      // -- seen in the listing, and the first MFMA then read the stale value: the hazard recognizer cannot know that the asm below is an MFMA and inserts
+      // nothing).  Five wait states between compiler code and the first MFMA of every asm sequence; tests/test_abi.py checks the disassembly for it.
+      asm volatile("s_nop 4");
+      static_for<MT * NT>([&](auto e_tag) {
+        constexpr int i = decltype(e_tag)::value / NT, j = decltype(e_tag)::value % NT;
+        if constexpr (st == 0) acc[i][j] = w4_mfma0(b2f[S][j], a2f[S][i]);
+        else acc[i][j] = w4_mfma(acc[i][j], b2f[S][j], a2f[S][i]);
+      });
+      if constexpr (st + 2 < KEXT) kext_load(std::integral_constant<int, S>{}, st + 2);
+    });
   }
   {
     const char* hA = tile_base(p.A, clampt(t_begin + 1));
@@ -1000,6 +1022,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   k_loop(std::integral_constant<int, 0>{});
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   static_for<16>([&](auto q_tag) { w4_keep(g[decltype(q_tag)::value]); });   // the staging registers stay allocated until their last loads have landed
+  asm volatile("s_nop 4");   // (compiler code may sit between the loop and the last deferred row's MFMAs: same hazard as in the prologue)
   static_for<NT>([&](auto j_tag) { constexpr int j = decltype(j_tag)::value; acc[MT - 1][j] = w4_mfma(acc[MT - 1][j], b1[j], a_def); });
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // the compiler's hazard recognizer does not see the asm MFMAs' AGPR writes
   OVLA_STAMP(3);
@@ -1713,10 +1736,10 @@ int launch_pipe(GemmParams& p, hipStream_t stream) {
   return OVLA_OK;
 }
 
-template <bool KEXT, int ABL = 0>
+template <int KEXT, int ABL = 0>
 int launch_w4(GemmParams& p, hipStream_t stream, int64_t ws_bytes, bool hybrid) {
-  if (p.K % BK != 0 || p.K2 != (KEXT ? 32 : 0) || !p.fast_addr || p.a_group_n > 0 || p.rowsq_out || p.rowscale_part || (p.k2_group_n > 0 && (p.k2_group_n % 256) != 0)) {
-    ovla_set_error("ovla_gemm_bf16: the 4-wave 256x256 config needs K %% 64 == 0, a K-extension of 0 or 32 and no block-diagonal / RMSNorm-fold mode");
+  if (p.K % BK != 0 || p.K2 != 32 * KEXT || !p.fast_addr || p.a_group_n > 0 || p.rowsq_out || p.rowscale_part || (p.k2_group_n > 0 && (p.k2_group_n % 256) != 0)) {
+    ovla_set_error("ovla_gemm_bf16: the 4-wave 256x256 config needs K %% 64 == 0, a K-extension of 0, 32, 64 or 96 and no block-diagonal / RMSNorm-fold mode");
     return OVLA_EINVAL;
   }
   p.tiles_m = cdiv(p.M, 256);
@@ -1890,9 +1913,9 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
       hybrid = true;
       tile = pick_tile(p.M, p.N, T, p.k2_group_n, wsb / 4, nullptr);
       // The 4-wave config of the 256x256 tile (hand-scheduled K loop) where it measured ahead of the 8-wave one (tools/gemm_w4_probe.py: +4...9 % per launch on
-      // the decoder shapes): K >= 4096 in whole K tiles, LoRA rank 0 or 32, the alpha / bias / residual or the RoPE epilogue.  OVLA_GEMM_W4=0 switches it off.
+      // the decoder shapes): K >= 4096 in whole K tiles, a LoRA K-extension of 0 / 32 / 64 / 96 columns, the alpha / bias / residual or the RoPE epilogue.  OVLA_GEMM_W4=0 switches it off.
       static const bool w4_on = []() { const char* e = getenv("OVLA_GEMM_W4"); return !(e && e[0] == '0'); }();
-      if (w4_on && tile == 17 && p.K >= 4096 && (p.K % BK) == 0 && (p.K2 == 0 || p.K2 == 32) && (p.k2_group_n % 256) == 0 && p.fast_addr &&
+      if (w4_on && tile == 17 && p.K >= 4096 && (p.K % BK) == 0 && (p.K2 == 0 || p.K2 == 32 || p.K2 == 64 || p.K2 == 96) && (p.k2_group_n % 256) == 0 && p.fast_addr &&
           (p.fast_epi || (a->rope_cos && rope_plain)) && p.act == OVLA_ACT_NONE && !a->C_pre && !a->colscale && !a->rowsq_out && !a->rowscale_part && p.split_k <= 1)
         tile = 18;
     }
@@ -1945,15 +1968,23 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     case 116: return launch_cfg<256, 256, 4, 2>(p, stream, wsb, true);
     case 17: return launch_cfg<256, 256, 2, 4>(p, stream, wsb, hybrid);   // 2x4 waves (128x64 wave tiles)
     case 117: return launch_cfg<256, 256, 2, 4>(p, stream, wsb, true);
-    case 18: return p.K2 > 0 ? launch_w4<true>(p, stream, wsb, hybrid) : launch_w4<false>(p, stream, wsb, hybrid);   // 4-wave 256x256, register-staged operands, hand-scheduled K loop
-    case 118: return p.K2 > 0 ? launch_w4<true>(p, stream, wsb, true) : launch_w4<false>(p, stream, wsb, true);
+    case 18: case 118: {   // 4-wave 256x256, register-staged operands, hand-scheduled K loop
+      const bool hy = hybrid || tile == 118;
+      switch (p.K2) {
+        case 0: return launch_w4<0>(p, stream, wsb, hy);
+        case 32: return launch_w4<1>(p, stream, wsb, hy);
+        case 64: return launch_w4<2>(p, stream, wsb, hy);
+        case 96: return launch_w4<3>(p, stream, wsb, hy);
+        default: ovla_set_error("ovla_gemm_bf16: the 4-wave 256x256 config takes a K-extension of 0, 32, 64 or 96 columns, not %d", p.K2); return OVLA_EINVAL;
+      }
+    }
 #ifdef OVLA_GEMM_ABLATE
-    case 218: return launch_w4<false, 1>(p, stream, wsb, false);
-    case 318: return launch_w4<false, 2>(p, stream, wsb, false);
-    case 418: return launch_w4<false, 3>(p, stream, wsb, false);
-    case 518: return launch_w4<false, 4>(p, stream, wsb, false);    // no lgkmcnt waits in the rows (wrong results, timing only)
-    case 618: return launch_w4<false, 8>(p, stream, wsb, false);    // no vmcnt waits in the rows
-    case 718: return launch_w4<false, 12>(p, stream, wsb, false);   // neither
+    case 218: return launch_w4<0, 1>(p, stream, wsb, false);
+    case 318: return launch_w4<0, 2>(p, stream, wsb, false);
+    case 418: return launch_w4<0, 3>(p, stream, wsb, false);
+    case 518: return launch_w4<0, 4>(p, stream, wsb, false);    // no lgkmcnt waits in the rows (wrong results, timing only)
+    case 618: return launch_w4<0, 8>(p, stream, wsb, false);    // no vmcnt waits in the rows
+    case 718: return launch_w4<0, 12>(p, stream, wsb, false);   // neither
 #endif
     case 101: return launch_cfg<128, 128, 2, 2>(p, stream, wsb, true);
     case 102: return launch_cfg<64, 128, 1, 4>(p, stream, wsb, true);

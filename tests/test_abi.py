@@ -134,7 +134,8 @@ def test_w4_gemm_loop_is_what_the_source_wrote(libmod, tmp_path):
         text = subprocess.run([str(objdump), "-d", str(o)], check=True, capture_output=True, text=True).stdout
         for m in re.finditer(r"<(_ZN\S*gemm_nt_w4_kernel\S*)>:\n(.*?)(?=\n\n|\Z)", text, re.S):
             ins = [ln.split("//")[0].split("\t")[1].strip() if "\t" in ln else ln.strip() for ln in m.group(2).splitlines() if ln.strip()]
-            ops = [i.split()[0] for i in ins if i and not i.endswith(":")]
+            ins = [i for i in ins if i and not i.endswith(":")]
+            ops = [i.split()[0] for i in ins]
             barriers = [k for k, op in enumerate(ops) if op == "s_barrier"]
             # the K loop = the stretch between the first and the last s_barrier that is followed by MFMAs (main loop x2 bodies + the odd tail body);
             # the epilogue's barrier (__syncthreads) comes after the last MFMA
@@ -150,4 +151,26 @@ def test_w4_gemm_loop_is_what_the_source_wrote(libmod, tmp_path):
             assert c("ds_read_b128") == 3 * 32 and c("ds_write_b128") == 2 * 16 and c("global_load_dwordx4") == 2 * 16, (c("ds_read_b128"), c("ds_write_b128"), c("global_load_dwordx4"))
             alien = [op for op in loop if op.startswith(("v_", "scratch_", "buffer_", "flat_")) and not op.startswith("v_mfma")]
             assert not alien, f"{m.group(1)}: the compiler put {sorted(set(alien))} inside the hand-scheduled K loop"
-    assert seen == 2, f"{seen} gemm_nt_w4_kernel instantiations found in the shipped library (with and without the K-extension expected)"
+            # everywhere in the kernel (the K-extension prologue included): no compiler-generated vector ALU instruction may WRITE a register an asm MFMA
+            # reads within the three instructions before it -- the hazard recognizer does not see that the asm reads the register (a v_mov right before the
+            # first K-extension MFMA once fed it a stale fragment); the source puts `s_nop 4` between compiler code and every MFMA sequence
+            def regs(tok):
+                mm = re.match(r"([va])\[(\d+):(\d+)\]", tok) or re.match(r"([va])(\d+)$", tok)
+                if not mm:
+                    return set()
+                lo = int(mm.group(2)); hi = int(mm.group(3)) if mm.lastindex == 3 else lo
+                return {(mm.group(1), r) for r in range(lo, hi + 1)}
+            for k, line in enumerate(ins):
+                if line.startswith("v_mfma"):
+                    toks = [x.strip() for x in line.split(None, 1)[1].split(",")]
+                    src = regs(toks[1]) | regs(toks[2])
+                    for back in range(1, 4):
+                        if k - back < 0:
+                            break
+                        prev = ins[k - back]
+                        if prev.startswith("s_nop"):
+                            break
+                        if prev.startswith("v_") and not prev.startswith("v_mfma"):
+                            dst = regs(prev.split(None, 1)[1].split(",")[0].strip())
+                            assert not (dst & src), f"{m.group(1)}: `{prev}` writes a source of `{line}` {back} instruction(s) before it"
+    assert seen == 4, f"{seen} gemm_nt_w4_kernel instantiations found in the shipped library (K-extensions of 0 / 32 / 64 / 96 columns expected)"

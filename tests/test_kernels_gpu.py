@@ -127,7 +127,7 @@ W4_SHAPES = [(128, 128, 64), (1000, 512, 1024), (300, 520, 192), (515, 1152, 115
 
 @pytest.mark.parametrize("M,N,K", W4_SHAPES)
 @pytest.mark.parametrize("tile", [18, 118])
-@pytest.mark.parametrize("variant", ["plain", "lora", "lora3", "bias_res", "gelu_pre", "split2"])
+@pytest.mark.parametrize("variant", ["plain", "lora", "lora64", "lora96", "lora3", "bias_res", "gelu_pre", "split2"])
 def test_gemm_w4_config(ops, dev, M, N, K, tile, variant):
     """The 4-wave 256x256 configuration (tiles 18 / 118 = with the hybrid remainder schedule; hand-scheduled inline-asm K loop, LoRA K-extension as a
     prologue, read-back epilogues) against torch fp32 on the same bf16 operands: odd and even K-tile counts, edge tiles, every epilogue path, split-K."""
@@ -137,6 +137,11 @@ def test_gemm_w4_config(ops, dev, M, N, K, tile, variant):
     kw = {}
     if variant in ("lora", "bias_res", "gelu_pre"):
         t, lb = rnd(M, 32, dev=dev), rnd(N, 32, dev=dev, scale=0.2)
+        kw.update(a2=t, b2=lb)
+        ref = ref + t.float() @ lb.float().T
+    if variant in ("lora64", "lora96"):   # the data-gradient GEMMs of the grouped LoRA linears: one 64- / 96-column K-extension, no column groups
+        k2 = int(variant[4:])
+        t, lb = rnd(M, k2, dev=dev), rnd(N, k2, dev=dev, scale=0.2)
         kw.update(a2=t, b2=lb)
         ref = ref + t.float() @ lb.float().T
     if variant == "lora3":
