@@ -1915,7 +1915,8 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
       // The 4-wave config of the 256x256 tile (hand-scheduled K loop) where it measured ahead of the 8-wave one (tools/gemm_w4_probe.py: +4...9 % per launch on
       // the decoder shapes): K >= 4096 in whole K tiles, a LoRA K-extension of 0 / 32 / 64 / 96 columns, the alpha / bias / residual or the RoPE epilogue.  OVLA_GEMM_W4=0 switches it off.
       static const bool w4_on = []() { const char* e = getenv("OVLA_GEMM_W4"); return !(e && e[0] == '0'); }();
-      if (w4_on && tile == 17 && p.K >= 4096 && (p.K % BK) == 0 && (p.K2 == 0 || p.K2 == 32 || p.K2 == 64 || p.K2 == 96) && (p.k2_group_n % 256) == 0 && p.fast_addr &&
+      static const int w4_min_k = []() { const char* e = getenv("OVLA_GEMM_W4_MINK"); return e ? atoi(e) : 4096; }();   // tuning switch
+      if (w4_on && tile == 17 && p.K >= w4_min_k && (p.K % BK) == 0 && (p.K2 == 0 || p.K2 == 32 || p.K2 == 64 || p.K2 == 96) && (p.k2_group_n % 256) == 0 && p.fast_addr &&
           (p.fast_epi || (a->rope_cos && rope_plain)) && p.act == OVLA_ACT_NONE && !a->C_pre && !a->colscale && !a->rowsq_out && !a->rowscale_part && p.split_k <= 1)
         tile = 18;
     }
