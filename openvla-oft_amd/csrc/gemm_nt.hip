@@ -768,15 +768,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmParams 
   }
 }
 
-// ---- experiment: 256x256 tile on FOUR waves (one per SIMD, 128x128 per wave, 256 accumulator registers in AGPRs), register-staged operands ------
-// The 8-wave kernel above reads (128 + 64) fragment rows per wave and K step from LDS (192 KB per K tile and CU) and pays 60-150 cycles of issue per
-// LDS-DMA piece; its ablations put the staging at 13 % and the fragment reads at 9 % of the loop.  Four 128x128 waves read 128 KB per K tile, and with
-// one wave per SIMD nothing but that wave's own instruction stream can fill the MFMA shadows -- so operands come by plain global_load_dwordx4 into
-// registers (a few cycles of issue each) and go to LDS by ds_write_b128, one of each per MFMA row, one K tile ahead.  The compiler cannot hold 256
-// accumulators + 170 live VGPRs through its own scheduling (it rotates the accumulators through copies and spills: 736 v_accvgpr moves and 267
-// scratch stores per K tile were measured in its listing), so the K loop is written out instruction by instruction in inline asm: the accumulators
-// are tied AGPR operands ("+a"), every wait count is explicit (all memory operations of the loop are in the asm, in program order, so the counts are
-// constants).  K % 64 == 0, no K-extension.
+// =====================================================================================================================
+// The 256x256 tile on FOUR waves (one per SIMD, 128x128 per wave, 256 accumulator registers in AGPRs), register-staged operands, hand-scheduled K loop.
+// `tile = 0` takes it instead of the 8-wave kernel above for K >= 4096 in whole K tiles, a LoRA K-extension of 0 / 32 / 64 / 96 columns and the alpha / bias /
+// residual or RoPE epilogue (ovla_gemm_bf16): every decoder projection of the fine-tune step, forward and data-gradient; launches 4-9 % faster there.
+//   * The 8-wave kernel reads (128 + 64) fragment rows per wave and K step from LDS (192 KB per K tile and CU) and pays 60-150 cycles of issue per LDS-DMA
+//     piece.  Four 128x128 waves read 128 KB per K tile; operands come by plain global_load_dwordx4 into registers (a few cycles of issue each) and go to LDS
+//     by ds_write_b128 one K tile later -- one load and one write per MFMA row.
+//   * With one wave per SIMD nothing but that wave's own instruction stream fills the MFMA shadows, and the wave issues in order: WHERE the other
+//     instructions sit decides the speed.  As a block between two rows of eight MFMAs they let the matrix pipe run dry (1.38 us per K tile); one after each
+//     of a row's first five MFMAs, with the fragment reads two rows ahead, they cost nothing extra.
+//   * The compiler cannot hold 256 accumulators + 170 live VGPRs through its own scheduling (its listing: 736 v_accvgpr moves and 267 scratch stores per K
+//     tile), so the K loop is inline asm, instruction by instruction: the accumulators are tied AGPR operands ("+a"), every wait count is explicit (all
+//     memory operations of the loop are in the asm, in program order, so the counts are constants).
+//   * Traps of this style, each hit once (tests/test_abi.py disassembles the shipped kernels and checks for them): an asm load whose result is never used
+//     is a DEAD output -- the compiler hands its destination registers to the next live value while the load is in flight (w4_keep, STAGE = false);
+//     an SGPR base the compiler produced with v_readfirstlane needs 5 wait states before an asm vector load reads it (tile_base); a compiler v_mov into a
+//     fragment register right before the first asm MFMA is not separated from it by the hazard recognizer, which cannot see into the asm (s_nop 4 before
+//     every MFMA sequence that follows compiler code); a branch around asm that updates the 64 accumulators makes the compiler merge them through scratch
+//     (straight-line code, template parameters instead of branches); one dynamically indexed use keeps the accumulator array in scratch memory.
+// Timing ablations (csrc/build.sh ablate, tools/gemm_w4_ablate.py): MFMAs + barriers alone 0.915 us per K tile (2.35 PFLOP/s), this loop 1.37.
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 OVLA_DEV f32x4 w4_mfma(f32x4 acc, bf16x8_bits x, bf16x8_bits y) { asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(x), "v"(y)); return acc; }
 OVLA_DEV f32x4 w4_mfma0(bf16x8_bits x, bf16x8_bits y) { f32x4 acc; asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(x), "v"(y)); return acc; }
