@@ -416,9 +416,9 @@ def main():
             d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fl
         ops.PROFILE = None
         # the dominant kernel = the gemm_nt instance with the most time in the step (ops._gemm_family names the instance each
-        # launch runs: t17 = gemm_nt_kernel<256,256,2,4>, t18 = its 4-wave configuration gemm_nt_w4_kernel, t1 = <128,128,2,2>, t2 = <64,128,1,4>, t5 = <128,32,4,1>; a launch's
+        # launch runs: t17 = gemm_nt_kernel<256,256,2,4>, t18k<KEXT> = its 4-wave configuration gemm_nt_w4_kernel<KEXT, 0> (KEXT = LoRA K-extension / 32), t1 = <128,128,2,2>, t2 = <64,128,1,4>, t5 = <128,32,4,1>; a launch's
         # events also cover its split-K / hybrid reduce kernel)
-        inst = {"gemm_nt_t17": "gemm_nt_kernel<256,256,2,4>", "gemm_nt_t18": "gemm_nt_w4_kernel<KEXT, 0> (the 256x256 tile on 4 waves; KEXT = 1 / 2 / 3: LoRA K-extension of 32 / 64 / 96 columns)", "gemm_nt_t1": "gemm_nt_kernel<128,128,2,2>",
+        inst = {"gemm_nt_t17": "gemm_nt_kernel<256,256,2,4>", "gemm_nt_t18k0": "gemm_nt_w4_kernel<0, 0>", "gemm_nt_t18k1": "gemm_nt_w4_kernel<1, 0>", "gemm_nt_t18k2": "gemm_nt_w4_kernel<2, 0>", "gemm_nt_t18k3": "gemm_nt_w4_kernel<3, 0>", "gemm_nt_t1": "gemm_nt_kernel<128,128,2,2>",
                 "gemm_nt_t2": "gemm_nt_kernel<64,128,1,4>", "gemm_nt_t5": "gemm_nt_kernel<128,32,4,1>", "gemm_nt_t6": "gemm_skinny_kernel<2>"}
         gemms = {k: v for k, v in fam.items() if k.startswith("gemm_nt")}
         dom = max(gemms, key=lambda k: gemms[k][1])

@@ -165,7 +165,8 @@ def _gemm_family(g):
 
     t = ctypes.c_int32()
     _lib.check(_lib.lib().ovla_gemm_resolved_tile(ctypes.byref(g), ctypes.byref(t)), "ovla_gemm_resolved_tile")
-    return f"gemm_nt_t{t.value % 100 if t.value >= 100 else t.value}"
+    tile = t.value % 100 if t.value >= 100 else t.value
+    return f"gemm_nt_t18k{g.K2 // 32}" if tile == 18 else f"gemm_nt_t{tile}"   # the 4-wave kernel is one instantiation per K-extension width
 
 
 def gemm_tn(x, y, *, out=None, alpha=1.0, accumulate=True, out_dtype=torch.float32):
