@@ -796,14 +796,43 @@ template <int OFF> OVLA_DEV void w4_ds_write(uint32_t addr, u32x4 src) { asm vol
 OVLA_DEV f32x4 w4_pin(f32x4 v) { asm volatile("" : "+a"(v)); return v; }
 OVLA_DEV void w4_keep(u32x4 v) { asm volatile("" : : "v"(v)); }
 OVLA_DEV u32x4 w4_gload(uint32_t voff, const char* sbase) { u32x4 dst; asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase)); return dst; }
-template <int KEXT, int ABL = 0>   // KEXT: 32-wide k-steps of the LoRA K-extension (0 .. 3);  ABL: timing-only ablations (OVLA_GEMM_ABLATE builds), bits: 1 = no staging after the prologue, 2 = no fragment reads, 4 = no lgkmcnt waits in the rows, 8 = no vmcnt waits in the rows
+// lgkmcnt a row of the 4-wave K loop needs before its first MFMA: LDS operations in program order are
+//   top: b0[0 .. NT-1], a(0), a(1), [w]        row k: a(k + 2) (k <= 13), b1[k] (k < NT), [w] (k < NPR)        ([w] = a staging ds_write, only with staging)
+// and everything NEWER than the youngest fragment row r uses -- a(r), and for the first row of the second k substep also b1[NT - 1] -- may stay in flight.
+constexpr int w4_newer(int r, bool stage, int NT, int NPR, bool TOPW) {
+  int ev[96] = {};
+  int n = 0;
+  for (int j = 0; j < NT; ++j) ev[n++] = 1;
+  ev[n++] = 100; ev[n++] = 101;
+  if (TOPW && stage) ev[n++] = 300;
+  for (int kk = 0; kk < r; ++kk) {
+    if (kk + 2 <= 15) ev[n++] = 100 + kk + 2;
+    if (kk < NT) ev[n++] = 200 + kk;
+    if (stage && kk < NPR) ev[n++] = 300;
+  }
+  int last = -1;
+  for (int e = 0; e < n; ++e)
+    if (ev[e] == 100 + r || (r == 8 && ev[e] == 200 + NT - 1)) last = e;
+  return n - 1 - last;
+}
+template <int KEXT, int ABL = 0, int WNW = 2, bool RMAP = false>   // WNW = waves along N: 2 -> the 256x256 tile (2 x 2 waves of 128x128), 4 -> a 128x256 tile (1 x 4 waves of 128x64: batch-1 shapes; RMAP: its column map for RoPE launches, below);  KEXT: 32-wide k-steps of the LoRA K-extension (0 .. 3);  ABL: timing-only ablations (OVLA_GEMM_ABLATE builds), bits: 1 = no staging after the prologue, 2 = no fragment reads, 4 = no lgkmcnt waits in the rows, 8 = no vmcnt waits in the rows
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
-  constexpr int BM = 256, BN = 256, WTM = 128, WTN = 128, MT = 8, NT = 8;
-  constexpr int TILE_BYTES = (BM + BN) * BK * 2;   // 65536
+  constexpr int WMW = 4 / WNW, BM = 128 * WMW, BN = 256, WTM = 128, WTN = BN / WNW, MT = 8, NT = WTN / 16;
+  constexpr int PA = BM / 32, PB = BN / 32, NP = PA + PB;   // 1-KiB staging pieces (8 rows x 128 bytes) per wave and K tile: of A, of B, together (16 / 12)
+  constexpr bool TOPW = NP == 16;                            // 16 pieces: one per MFMA row, the deferred row's slot at the top of a body included; 12: rows 0 .. 11
+  constexpr int NPR = TOPW ? NP - 1 : NP;                    // pieces carried by rows 0 .. NPR - 1
+  constexpr int TILE_BYTES = (BM + BN) * BK * 2;             // 65536 / 49152
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
+  // Column map of the wave's n-tiles.  Plain: wave wn owns columns wn * WTN + 16 j.  RMAP (128x256 configuration, RoPE launches: head_dim 128 = two 64-column
+  // wave strips): wave (h = wn >> 1, w2 = wn & 1) takes columns h * 128 + 32 w2 + [0, 32) AND their rotation partners + 64, i.e. tile j sits at
+  // 16 (j & 1) + 64 (j >> 1): the partner of a slab column is 32 slab columns away in the same row of the wave's own slab.
+  static_assert(!RMAP || WNW == 4, "the RoPE column map belongs to the 128x256 configuration");
+  const int cb = RMAP ? (wn >> 1) * 128 + (wn & 1) * 32 : wn * WTN;     // first column of the wave inside the tile
+  auto cj = [](int j) constexpr { return RMAP ? 16 * (j & 1) + 64 * (j >> 1) : 16 * j; };   // column of n-tile j relative to cb
+  auto scol = [](int sc) constexpr { return RMAP ? (sc & 31) + 64 * (sc >> 5) : sc; };      // column (relative to cb) of slab column sc = 16 j + c
   OVLA_STAMP(0);
 
   int bid = blockIdx.x;
@@ -850,33 +879,49 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
 
   // staging: piece i of this wave = rows (wave * 8 + i) * 8 .. + 7 of the A (i < 8) / B (i >= 8) tile; lane -> row + (lane >> 3), 16-byte chunk lane & 7
   // (eight lanes read one row's 128 contiguous bytes); the LDS image is the 8-wave kernel's (chunk XOR (row >> 1) & 7), applied on the WRITE address.
-  uint32_t offA[8], offB[8];
+  uint32_t offA[PA], offB[PB];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int r = (wave * 8 + i) * 8 + (lane >> 3);
-    int ga = m0 + r, gb = n0 + r;
+  for (int i = 0; i < PA; ++i) {
+    int ga = m0 + (wave * PA + i) * 8 + (lane >> 3);
     ga = ga < p.M - 1 ? ga : p.M - 1;
-    gb = gb < p.N - 1 ? gb : p.N - 1;
     offA[i] = (uint32_t)(((int64_t)ga * p.lda + (lane & 7) * 8) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    int gb = n0 + (wave * PB + i) * 8 + (lane >> 3);
+    gb = gb < p.N - 1 ? gb : p.N - 1;
     offB[i] = (uint32_t)(((int64_t)gb * p.ldb + (lane & 7) * 8) * 2);
   }
   // LDS byte addresses (VGPRs); the piece / m-tile index goes into the instruction's offset field
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem_raw;   // LDS addresses are 32-bit (the pointer's low word)
   const int wx = (lane & 7) ^ (lane >> 4);               // (r >> 1) & 7 = (4 (i & 1) + (lane >> 4)) & 7 for r = 8 (8 wave + i) + (lane >> 3)
-  const uint32_t w_even = lds0 + wave * 8192 + (lane >> 3) * 128 + wx * 16, w_odd = lds0 + wave * 8192 + (lane >> 3) * 128 + (wx ^ 4) * 16;
-  uint32_t wr[2][2] = {{w_even, w_odd}, {w_even + TILE_BYTES, w_odd + TILE_BYTES}};   // [buffer][piece parity]
-  const int arow = wm * WTM + (lane & 15), brow = wn * WTN + (lane & 15), cq = lane >> 4;
+  const uint32_t w_even = lds0 + (lane >> 3) * 128 + wx * 16, w_odd = lds0 + (lane >> 3) * 128 + (wx ^ 4) * 16;
+  const uint32_t wa = wave * PA * 1024, wb = BM * 128 + wave * PB * 1024;   // this wave's pieces of the A / B tile ((wave * P + i) & 1 = i & 1: PA and PB are even)
+  uint32_t wrA[2][2] = {{w_even + wa, w_odd + wa}, {w_even + wa + TILE_BYTES, w_odd + wa + TILE_BYTES}};   // [buffer][piece parity]; + 1024 i in the offset field
+  uint32_t wrB[2][2] = {{w_even + wb, w_odd + wb}, {w_even + wb + TILE_BYTES, w_odd + wb + TILE_BYTES}};
+  const int arow = wm * WTM + (lane & 15), brow = cb + (lane & 15), cq = lane >> 4;
   const uint32_t ra0 = lds0 + arow * 128 + ((cq ^ ((arow >> 1) & 7)) * 16), rb0 = lds0 + BM * 128 + brow * 128 + ((cq ^ ((brow >> 1) & 7)) * 16);
   uint32_t ra[2][2] = {{ra0, ra0 ^ 64}, {ra0 + TILE_BYTES, (ra0 ^ 64) + TILE_BYTES}};   // [buffer][k substep]: + 2048 i per m-tile in the offset field
   uint32_t rb[2][2] = {{rb0, rb0 ^ 64}, {rb0 + TILE_BYTES, (rb0 ^ 64) + TILE_BYTES}};
 
-  u32x4 g[16];
+  u32x4 g[NP];
   bf16x8_bits b0[NT], b1[NT];
   bf16x8_bits a_def = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int j = 0; j < NT; ++j) b1[j] = a_def;
 
   auto clampt = [&](int t) { return t < t_end ? t : t_end - 1; };
+  // staging piece q of this wave: q < PA -> A piece q, else B piece q - PA
+  auto piece_write = [&](auto buf_tag, auto q_tag) {
+    constexpr int BUF = decltype(buf_tag)::value, q = decltype(q_tag)::value < NP ? decltype(q_tag)::value : 0;   // (rows >= NP instantiate this in a discarded branch)
+    if constexpr (q < PA) w4_ds_write<q * 1024>(wrA[BUF][q & 1], g[q]);
+    else w4_ds_write<(q - PA) * 1024>(wrB[BUF][(q - PA) & 1], g[q]);
+  };
+  auto piece_load = [&](auto q_tag, const char* bA, const char* bB) {
+    constexpr int q = decltype(q_tag)::value < NP ? decltype(q_tag)::value : 0;
+    if constexpr (q < PA) g[q] = w4_gload(offA[q], bA);
+    else g[q] = w4_gload(offB[q - PA], bB);
+  };
   auto tile_base = [&](const bf16_bits* base, int t) {   // wave-uniform by construction; said explicitly, because the asm loads take it as an SGPR pair ("s")
     const uint64_t a = reinterpret_cast<uint64_t>(base) + (uint64_t)((int64_t)t * (BK * 2));
     uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
@@ -891,6 +936,20 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   // trip for the tile everything waits on; source chunk = slot XOR (row >> 1) & 7 as in the 8-wave kernel).  (3) The K-extension's 64 MFMAs per k-step run
   // while that tile is on its way.  (4) Tile t_begin + 1 into the staging registers, in the loop's order.  The compiler counts the vector memory operations
   // it knows (1, 2) when it waits for (1) before (3); the asm loads of (4) are invisible to it, so none of them may be issued before (3).
+  // RMSNorm fold, consumer side (128x256 configuration; ovla.h: rowscale_part): rstd of this tile's 128 rows from the producer's per-64-column sums of squares,
+  // into LDS behind the K-tile buffers.  Two lanes per row; the loads are issued first and waited for after the LDS-DMA of the first K tile has been issued.
+  float* s_rstd = reinterpret_cast<float*>(smem_raw + 2 * TILE_BYTES);
+  bool rowscale = false;
+  f32x4 rs_q[WNW == 4 ? 8 : 1];
+  if constexpr (WNW == 4) {
+    rowscale = p.rowscale_part != nullptr;
+    if (rowscale) {   // (rowscale_slots = K / 64 is a multiple of 8 and at most 64 here: host-checked)
+      const int m = m0 + (tid >> 1), per = p.rowscale_slots >> 1;
+      const float* src = p.rowscale_part + (int64_t)(m < p.M ? m : p.M - 1) * p.rowscale_slots + (tid & 1) * per;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rs_q[u] = (4 * u < per) ? *reinterpret_cast<const f32x4*>(src + 4 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   OVLA_STAMP(1);
   // (K2 = 32 KEXT, host-checked.  Straight-line code: a branch around asm that updates 64 accumulators makes the compiler merge them through scratch.  Two
   // fragment sets: steps 0 and 1 are requested up front, step 2 into set 0 once step 0's MFMAs have read it.)
@@ -902,7 +961,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) { int m = m0 + arow + i * 16; m = m < p.M - 1 ? m : p.M - 1; a2f[S][i] = *reinterpret_cast<const bf16x8_bits*>(a2p + (int64_t)m * p.lda2 + ks * 32); }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) { int n = n0 + brow + j * 16; n = n < p.N - 1 ? n : p.N - 1; b2f[S][j] = *reinterpret_cast<const bf16x8_bits*>(b2p + (int64_t)n * p.ldb2 + ks * 32); }
+    for (int j = 0; j < NT; ++j) { int n = n0 + brow + cj(j); n = n < p.N - 1 ? n : p.N - 1; b2f[S][j] = *reinterpret_cast<const bf16x8_bits*>(b2p + (int64_t)n * p.ldb2 + ks * 32); }
   };
   if constexpr (KEXT > 0) {
     const int a2_col0 = p.k2_group_n > 0 ? (n0 / p.k2_group_n) * p.K2 : 0;
@@ -917,11 +976,24 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
     const int sw = lane >> 4, c = lane & 7;
     const int d_even = ((c ^ sw) - c) * 16, d_odd = ((c ^ sw ^ 4) - c) * 16;   // source chunk of LDS slot (lane & 7) in piece i: slot XOR (4 (i & 1) + (lane >> 4))
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < PA; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + (int64_t)offA[i] + ((i & 1) ? d_odd : d_even)),
-                                       (__attribute__((address_space(3))) void*)(smem_raw + (wave * 8 + i) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(smem_raw + (wave * PA + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + (int64_t)offB[i] + ((i & 1) ? d_odd : d_even)),
-                                       (__attribute__((address_space(3))) void*)(smem_raw + BM * 128 + (wave * 8 + i) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(smem_raw + BM * 128 + (wave * PB + i) * 1024), 16, 0, 0);
+  }
+  if constexpr (WNW == 4) {
+    if (rowscale) {
+      float ssum = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { ssum += rs_q[u][0]; ssum += rs_q[u][1]; ssum += rs_q[u][2]; ssum += rs_q[u][3]; }
+      ssum += __shfl_xor(ssum, 1, 64);
+      const int m = m0 + (tid >> 1);
+      const float r = m < p.M ? rsqrtf(ssum / (float)(p.rowscale_slots * 64) + p.rowscale_eps) : 0.f;
+      s_rstd[tid >> 1] = r;
+      if ((tid & 1) == 0 && m < p.M && tn == 0 && split == 0 && p.rowscale_r) p.rowscale_r[m] = r;   // for the hybrid-remainder reduce kernel
     }
   }
   if constexpr (KEXT > 0) {
@@ -947,10 +1019,9 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   {
     const char* hA = tile_base(p.A, clampt(t_begin + 1));
     const char* hB = tile_base(p.B, clampt(t_begin + 1));
-    g[15] = w4_gload(offB[7], hB);   // the loop's order: piece 15 at the top of a body, then 0 .. 14 with the rows
-    static_for<8>([&](auto i_tag) { constexpr int i = decltype(i_tag)::value; g[i] = w4_gload(offA[i], hA); });
-    static_for<7>([&](auto i_tag) { constexpr int i = decltype(i_tag)::value; g[8 + i] = w4_gload(offB[i], hB); });
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the 16 LDS-DMA pieces of tile t_begin have landed (the 16 register loads behind them may still fly)
+    if constexpr (TOPW) piece_load(std::integral_constant<int, NP - 1>{}, hA, hB);   // the loop's order: (piece 15 at the top of a body,) then 0 .. NPR - 1 with the rows
+    static_for<NPR>([&](auto q_tag) { piece_load(q_tag, hA, hB); });
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NP) : "memory");   // the NP LDS-DMA pieces of tile t_begin have landed (the NP register loads behind them may still fly)
   }
 
   // body t (PAR = parity of t - t_begin = LDS buffer holding tile t).  Program order of memory operations per MFMA row r (0 .. 15; row 15 of tile t - 1 is
@@ -974,7 +1045,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
     bf16x8_bits af[3];
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier");   // tile t is in LDS (everyone's ds_writes), nobody reads the other buffer any more
     if constexpr (FRAG) {
-    static_for<NT>([&](auto j_tag) { constexpr int j = decltype(j_tag)::value; b0[j] = w4_ds_read<j * 2048>(rb[PAR][0]); });
+    static_for<NT>([&](auto j_tag) { constexpr int j = decltype(j_tag)::value; b0[j] = w4_ds_read<cj(j) * 128>(rb[PAR][0]); });
     af[0] = w4_ds_read<0>(ra[PAR][0]);
     af[1] = w4_ds_read<2048>(ra[PAR][0]);
     } else { af[0] = af[1] = af[2] = a_def; }
@@ -983,36 +1054,30 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
     static_for<NT>([&](auto j_tag) {
       constexpr int j = decltype(j_tag)::value;
       acc[MT - 1][j] = w4_mfma(acc[MT - 1][j], b1[j], a_def);
-      if constexpr (STAGE && j == SHIFT) { asm volatile("s_waitcnt vmcnt(15)"); w4_ds_write<7 * 1024 + BM * 128>(wr[PAR ^ 1][1], g[15]); }
-      if constexpr (STAGE && j == SHIFT + 1) g[15] = w4_gload(offB[7], gB);
+      if constexpr (STAGE && TOPW && j == SHIFT) { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NP - 1)); piece_write(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, NP - 1>{}); }
+      if constexpr (STAGE && TOPW && j == SHIFT + 1) piece_load(std::integral_constant<int, NP - 1>{}, gA, gB);
     });
     static_for<2 * MT - 1>([&](auto r_tag) {
       constexpr int r = decltype(r_tag)::value;
       constexpr int sub = r / MT, i = r % MT;
-      // youngest fragment row r uses: a(r) -- issued two rows earlier (a(0), a(1): at the top) -- except row MT, which also needs b1[MT - 1] (row MT - 1's
-      // last read).  Newer LDS operations, with / without staging:
-      //   r = 0: a(1), [w15]                      -> 2 / 1        r = 1: [w15], a(2), b1[0], [w0]                 -> 4 / 2
-      //   2 <= r <= MT - 1 and r = MT + 1: b1, [w], a, b1, [w]   (r = MT + 1: b1[MT-1], [w], a, [w])   -> 5 / 3 (4 / 2)
-      //   r = MT: [w(MT-1)]                       -> 1 / 0        r >= MT + 2: [w], a(r + 1), [w]                 -> 3 / 1
-      constexpr int newer = r == 0 ? (STAGE ? 2 : 1) : r == 1 ? (STAGE ? 4 : 2) : r < MT ? (STAGE ? 5 : 3) : r == MT ? (STAGE ? 1 : 0) : r == MT + 1 ? (STAGE ? 4 : 2) : (STAGE ? 3 : 1);
+      constexpr int newer = w4_newer(r, STAGE, NT, NPR, TOPW);   // (256x256: 2 / 4 / 5 ... 5 / 1 / 4 / 3 ... 3 with staging)
       if constexpr (FRAG && !(ABL & 4)) asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(newer));
       auto mf = [&](auto j_tag) {
         constexpr int j = decltype(j_tag)::value;
         if constexpr (sub == 0) acc[i][j] = w4_mfma(acc[i][j], b0[j], af[r % 3]);
         else acc[i][j] = w4_mfma(acc[i][j], b1[j], af[r % 3]);
       };
-      // one memory instruction per MFMA gap: a-fragment read, b-fragment read, vmcnt, ds_write, global load after MFMAs SHIFT .. SHIFT + 4
+      // one memory instruction per MFMA gap: a-fragment read, b-fragment read, vmcnt, ds_write, global load after MFMAs SHIFT .. SHIFT + 4 (with four MFMAs per
+      // row -- the 128x256 configuration -- the wait and the write share a gap)
       static_for<NT>([&](auto j_tag) {
-        constexpr int j = decltype(j_tag)::value, k = j - SHIFT;
+        constexpr int j = decltype(j_tag)::value, kk = j - SHIFT;
+        constexpr int K_V = 2, K_W = NT >= 5 ? 3 : 2, K_G = NT >= 5 ? 4 : 3;
         mf(j_tag);
-        if constexpr (k == 0 && FRAG && r + 2 <= 2 * MT - 1) af[(r + 2) % 3] = w4_ds_read<((r + 2) % MT) * 2048>(ra[PAR][(r + 2) / MT]);
-        if constexpr (k == 1 && FRAG && sub == 0) b1[i] = w4_ds_read<i * 2048>(rb[PAR][1]);
-        if constexpr (k == 2 && STAGE && !(ABL & 8)) asm volatile("s_waitcnt vmcnt(15)");
-        if constexpr (k == 3 && STAGE) w4_ds_write<(r & 7) * 1024 + (r < 8 ? 0 : BM * 128)>(wr[PAR ^ 1][r & 1], g[r]);
-        if constexpr (k == 4 && STAGE) {
-          if constexpr (r < 8) g[r] = w4_gload(offA[r], gA);
-          else g[r] = w4_gload(offB[r - 8], gB);
-        }
+        if constexpr (kk == 0 && FRAG && r + 2 <= 2 * MT - 1) af[(r + 2) % 3] = w4_ds_read<((r + 2) % MT) * 2048>(ra[PAR][(r + 2) / MT]);
+        if constexpr (kk == 1 && FRAG && sub == 0 && i < NT) b1[i] = w4_ds_read<cj(i) * 128>(rb[PAR][1]);
+        if constexpr (kk == K_V && STAGE && r < NPR && !(ABL & 8)) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NP - 1));
+        if constexpr (kk == K_W && STAGE && r < NPR) piece_write(std::integral_constant<int, PAR ^ 1>{}, r_tag);
+        if constexpr (kk == K_G && STAGE && r < NPR) piece_load(r_tag, gA, gB);
       });
     });
     a_def = af[(2 * MT - 1) % 3];
@@ -1032,7 +1097,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   // 140 moves per K tile -- and a time skew of w x 8..96 cycles after the barrier, which only added its own length to every K tile.)
   k_loop(std::integral_constant<int, 0>{});
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  static_for<16>([&](auto q_tag) { w4_keep(g[decltype(q_tag)::value]); });   // the staging registers stay allocated until their last loads have landed
+  static_for<NP>([&](auto q_tag) { w4_keep(g[decltype(q_tag)::value]); });   // the staging registers stay allocated until their last loads have landed
   asm volatile("s_nop 4");   // (compiler code may sit between the loop and the last deferred row's MFMAs: same hazard as in the prologue)
   static_for<NT>([&](auto j_tag) { constexpr int j = decltype(j_tag)::value; acc[MT - 1][j] = w4_mfma(acc[MT - 1][j], b1[j], a_def); });
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");   // the compiler's hazard recognizer does not see the asm MFMAs' AGPR writes
@@ -1043,14 +1108,14 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
     float* slab = p.ws + (int64_t)rem_unit * (BM * BN);
     static_for<MT * NT>([&](auto e_tag) {
       constexpr int i = decltype(e_tag)::value / NT, j = decltype(e_tag)::value % NT;
-      *reinterpret_cast<f32x4*>(slab + (wm * WTM + i * 16 + (lane & 15)) * BN + wn * WTN + j * 16 + 4 * (lane >> 4)) = acc[i][j];
+      *reinterpret_cast<f32x4*>(slab + (wm * WTM + i * 16 + (lane & 15)) * BN + cb + cj(j) + 4 * (lane >> 4)) = acc[i][j];
     });
     return;
   }
   if (p.split_k > 1) {
     static_for<MT * NT>([&](auto e_tag) {
       constexpr int i = decltype(e_tag)::value / NT, j = decltype(e_tag)::value % NT;
-      const int m = m0 + wm * WTM + i * 16 + (lane & 15), n = n0 + wn * WTN + j * 16 + 4 * (lane >> 4);
+      const int m = m0 + wm * WTM + i * 16 + (lane & 15), n = n0 + cb + cj(j) + 4 * (lane >> 4);
       if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(p.ws + ((int64_t)split * p.M + m) * p.N + n) = acc[i][j];
     });
     return;
@@ -1061,8 +1126,9 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   // permuted so that a lane's tile pair is 8 consecutive columns, 16 rows x 64 bytes per store instruction -- measured 7 % slower per tile than this.)
   constexpr int LDSW = WTN + 4;
   float* slab = reinterpret_cast<float*>(smem_raw) + wave * (32 * LDSW);
-  const int mbase = m0 + wm * WTM, nbase = n0 + wn * WTN;
+  const int mbase = m0 + wm * WTM, nbase = n0 + cb;   // (RMAP: a slab column sc is output column nbase + scol(sc))
   __syncthreads();   // nobody reads the K tiles any more; from here on a wave touches only its own slab
+  constexpr int OCT = WTN / 8, STEPS = 32 * OCT / 64;   // 8-column groups per slab row; read-back steps per round (8 / 4)
   auto to_slab = [&](auto rd_tag) {
     constexpr int rd = decltype(rd_tag)::value;
     static_for<2 * NT>([&](auto e_tag) {
@@ -1072,7 +1138,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
   const bool interior = m0 + BM <= p.M && n0 + BN <= p.N;
-  if (p.rope_cos && nbase < p.rope_cols) {   // RoPE (head_dim 128 = this wave's 128 columns): the rotation partner of octet c8 is octet c8 ^ 8 of the same slab row
+  if (WNW == 2 && p.rope_cos && nbase < p.rope_cols) {   // RoPE, 256x256 configuration (head_dim 128 = this wave's 128 columns): the rotation partner of octet c8 is octet c8 ^ 8 of the same slab row
     static_for<MT / 2>([&](auto rd_tag) {
       constexpr int rd = decltype(rd_tag)::value;
       bf16x8_bits csv[8], snv[8];
@@ -1108,33 +1174,74 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
     });
     return;
   }
+  if constexpr (RMAP) {
+    if (p.rope_cos && n0 + (wn >> 1) * 128 < p.rope_cols) {   // RoPE, 128x256 configuration: slab columns [0, 32) are the lower-half columns 32 w2 + c of the head, [32, 64) their partners + 64
+      static_for<MT / 2>([&](auto rd_tag) {
+        constexpr int rd = decltype(rd_tag)::value;
+        bf16x8_bits csv[STEPS], snv[STEPS];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+          const int idx = st * 64 + lane, row = idx / OCT, c8 = idx % OCT;
+          const int m = mbase + rd * 32 + row, cin = (wn & 1) * 32 + (c8 & 3) * 8;
+          const int pos = (m < p.M ? m : p.M - 1) % p.rope_S;
+          csv[st] = *reinterpret_cast<const bf16x8_bits*>(p.rope_cos + (int64_t)pos * 64 + cin);
+          snv[st] = *reinterpret_cast<const bf16x8_bits*>(p.rope_sin + (int64_t)pos * 64 + cin);
+        }
+        to_slab(rd_tag);
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+          const int idx = st * 64 + lane, row = idx / OCT, c8 = idx % OCT;
+          const float* xs = slab + row * LDSW + c8 * 8;
+          const float* ys = slab + row * LDSW + (c8 ^ 4) * 8;
+          const f32x4 xlo = *reinterpret_cast<const f32x4*>(xs), xhi = *reinterpret_cast<const f32x4*>(xs + 4);
+          const f32x4 ylo = *reinterpret_cast<const f32x4*>(ys), yhi = *reinterpret_cast<const f32x4*>(ys + 4);
+          const int m = mbase + rd * 32 + row, n = nbase + scol(c8 * 8);
+          const bool upper = c8 >= 4;
+          const float ra = p.alpha * (rowscale ? s_rstd[rd * 32 + row] : 1.f);
+          const bf16x8_bits cs = csv[st], sn = snv[st];
+          bf16x8_bits o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {    // rope_kernel's arithmetic on y = bf16(acc): lo' = bf16(a c) + bf16(-b s), hi' = bf16(b c) + bf16(a s)
+            const float x = bfround((e < 4 ? xlo[e] : xhi[e - 4]) * ra), y = bfround((e < 4 ? ylo[e] : yhi[e - 4]) * ra);
+            const float cc = bf2f((bf16_bits)cs[e]), sv = bf2f((bf16_bits)sn[e]);
+            o[e] = (short)f2bf(upper ? bfround(x * cc) + bfround(y * sv) : bfround(x * cc) + bfround(-y * sv));
+          }
+          if (m < p.M && n < p.N) *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      });
+      return;
+    }
+  }
   if (p.fast_epi && interior && p.act == OVLA_ACT_NONE && !p.Cpre && !p.colscale) {   // alpha, bias, residual: every Llama projection, forward and data-gradient
     static_for<MT / 2>([&](auto rd_tag) {
       constexpr int rd = decltype(rd_tag)::value;
-      constexpr int GRP = 8;
+      constexpr int GRP = STEPS;
       bf16x8_bits r8[GRP];
       if (p.residual) {
 #pragma unroll
         for (int s2 = 0; s2 < GRP; ++s2) {
-          const int idx = s2 * 64 + lane, row = idx >> 4, c8 = idx & 15;
-          r8[s2] = *reinterpret_cast<const bf16x8_bits*>(p.residual + (int64_t)(mbase + rd * 32 + row) * p.ldr + nbase + c8 * 8);
+          const int idx = s2 * 64 + lane, row = idx / OCT, c8 = idx % OCT;
+          r8[s2] = *reinterpret_cast<const bf16x8_bits*>(p.residual + (int64_t)(mbase + rd * 32 + row) * p.ldr + nbase + scol(c8 * 8));
         }
       }
       to_slab(rd_tag);
       f32x4 lo[GRP], hi[GRP];
 #pragma unroll
       for (int s2 = 0; s2 < GRP; ++s2) {
-        const int idx = s2 * 64 + lane, row = idx >> 4, c8 = idx & 15;
+        const int idx = s2 * 64 + lane, row = idx / OCT, c8 = idx % OCT;
         lo[s2] = *reinterpret_cast<const f32x4*>(slab + row * LDSW + c8 * 8);
         hi[s2] = *reinterpret_cast<const f32x4*>(slab + row * LDSW + c8 * 8 + 4);
       }
 #pragma unroll
       for (int s2 = 0; s2 < GRP; ++s2) {
-        const int idx = s2 * 64 + lane, row = idx >> 4, c8 = idx & 15;
-        const int m = mbase + rd * 32 + row, n = nbase + c8 * 8;
+        const int idx = s2 * 64 + lane, row = idx / OCT, c8 = idx % OCT;
+        const int m = mbase + rd * 32 + row, n = nbase + scol(c8 * 8);
         float x[8];
+        float ra = p.alpha;
+        if constexpr (WNW == 4) { if (rowscale) ra *= s_rstd[rd * 32 + row]; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { x[e] = lo[s2][e] * p.alpha; x[4 + e] = hi[s2][e] * p.alpha; }
+        for (int e = 0; e < 4; ++e) { x[e] = lo[s2][e] * ra; x[4 + e] = hi[s2][e] * ra; }
         if (p.bias) {
           const bf16x8_bits b8 = *reinterpret_cast<const bf16x8_bits*>(p.bias + n);
 #pragma unroll
@@ -1149,6 +1256,15 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
         bf16x8_bits o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(x[e]);
+        if constexpr (WNW == 4 && !RMAP) {
+          if (p.rowsq_out) {   // RMSNorm fold, producer side: this wave's slab row IS one 64-column group: 8 lanes x 8 stored (bf16-rounded) values
+            float sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = bf2f((bf16_bits)o[e]); sq += f * f; }
+            sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+            if (c8 == 0) p.rowsq_out[(int64_t)m * (p.N >> 6) + (nbase >> 6)] = sq;
+          }
+        }
         *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1164,10 +1280,21 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
     constexpr int rd = decltype(rd_tag)::value;
     to_slab(rd_tag);
 #pragma unroll 1
-    for (int it = 0; it < 16; ++it) {
-      const int idx = it * 64 + lane, row = idx >> 5, c4 = idx & 31;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * LDSW + c4 * 4);
-      const int m = mbase + rd * 32 + row, n = nbase + c4 * 4;
+    for (int it = 0; it < WTN / 8; ++it) {
+      const int idx = it * 64 + lane, row = idx / (WTN / 4), c4 = idx % (WTN / 4);
+      f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * LDSW + c4 * 4);
+      const int m = mbase + rd * 32 + row, n = nbase + scol(c4 * 4);
+      if constexpr (WNW == 4) {   // (one slab row = one 64-column group, read back by 16 consecutive lanes; N % 64 == 0 with the fold: the 16 lanes are inside or outside together)
+        if (rowscale) v *= s_rstd[rd * 32 + row];
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+        const bool inside = m < p.M && n < p.N;
+        if (inside) st = epilogue_store(p, m, n, v);
+        if (!RMAP && p.rowsq_out) {
+          const float sq = rowsq16(st);
+          if (inside && c4 == 0) p.rowsq_out[(int64_t)m * (p.N >> 6) + (n >> 6)] = sq;
+        }
+        continue;
+      }
       if (m < p.M && n < p.N) epilogue_store(p, m, n, v);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1747,17 +1874,22 @@ int launch_pipe(GemmParams& p, hipStream_t stream) {
   return OVLA_OK;
 }
 
-template <int KEXT, int ABL = 0>
+template <int KEXT, int ABL = 0, int WNW = 2, bool RMAP = false>
 int launch_w4(GemmParams& p, hipStream_t stream, int64_t ws_bytes, bool hybrid) {
-  if (p.K % BK != 0 || p.K2 != 32 * KEXT || !p.fast_addr || p.a_group_n > 0 || p.rowsq_out || p.rowscale_part || (p.k2_group_n > 0 && (p.k2_group_n % 256) != 0)) {
-    ovla_set_error("ovla_gemm_bf16: the 4-wave 256x256 config needs K %% 64 == 0, a K-extension of 0, 32, 64 or 96 and no block-diagonal / RMSNorm-fold mode");
+  constexpr int BM = 128 * (4 / WNW), BN = 256;
+  if (p.K % BK != 0 || p.K2 != 32 * KEXT || !p.fast_addr || p.a_group_n > 0 || (p.k2_group_n > 0 && (p.k2_group_n % 256) != 0)) {
+    ovla_set_error("ovla_gemm_bf16: the 4-wave configs need K %% 64 == 0, a K-extension of 0, 32, 64 or 96 columns and no block-diagonal mode");
     return OVLA_EINVAL;
   }
-  p.tiles_m = cdiv(p.M, 256);
-  p.tiles_n = cdiv(p.N, 256);
+  if ((p.rowsq_out || p.rowscale_part) && (WNW != 4 || (p.rowscale_part && p.rowscale_slots > 64) || (p.rowsq_out && RMAP))) {
+    ovla_set_error("ovla_gemm_bf16: among the 4-wave configs the RMSNorm fold runs on the 128x256 one only (rowscale_part: K <= 4096)");
+    return OVLA_EINVAL;
+  }
+  p.tiles_m = cdiv(p.M, BM);
+  p.tiles_n = cdiv(p.N, BN);
   const int splits = p.split_k > 1 ? p.split_k : 1;
-  const size_t lds = (size_t)2 * 512 * BK * sizeof(bf16_bits);
-  auto kern = gemm_nt_w4_kernel<KEXT, ABL>;
+  const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16_bits) + (WNW == 4 ? 128 * sizeof(float) : 0);   // + s_rstd of the RMSNorm fold
+  auto kern = gemm_nt_w4_kernel<KEXT, ABL, WNW, RMAP>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1766,7 +1898,8 @@ int launch_w4(GemmParams& p, hipStream_t stream, int64_t ws_bytes, bool hybrid) 
   const int tiles = p.tiles_m * p.tiles_n;
   p.full_tiles = tiles; p.rem_tiles = 0; p.rem_splits = 1;
   if (hybrid && splits == 1 && p.ws != nullptr) {
-    const HybridPlan pl = plan_hybrid(p.M, p.N, p.T1 + p.T2, tile_cfg(256, 256), ws_bytes / 4);   // (same plan as the 8-wave config; the K-extension is not a K tile here)
+    static const TileCfg cfg128 = {22, 128, 256, 1, 1.2e15, 5e-6, 0.0};   // (not in kTileCfgs: tile = 0 does not pick this configuration by itself)
+    const HybridPlan pl = plan_hybrid(p.M, p.N, p.T1 + p.T2, WNW == 2 ? tile_cfg(256, 256) : cfg128, ws_bytes / 4);   // (256x256: same plan as the 8-wave config; the K-extension is not a K tile here)
     p.full_tiles = pl.full_tiles; p.rem_tiles = pl.rem_tiles; p.rem_splits = pl.rem_splits;
   }
   p.hyb_cnt = nullptr;
@@ -1774,7 +1907,7 @@ int launch_w4(GemmParams& p, hipStream_t stream, int64_t ws_bytes, bool hybrid) 
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, stream, p);
   OVLA_CHECK_LAUNCH("ovla_gemm_bf16(w4)");
   if (p.rem_tiles > 0) {
-    hipLaunchKernelGGL((gemm_hybrid_reduce_kernel<256, 256>), dim3(256 * 256 / 4 / 256 / 4, p.rem_tiles), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((gemm_hybrid_reduce_kernel<BM, BN>), dim3(BM * BN / 4 / 256 / 4, p.rem_tiles), dim3(256), 0, stream, p);
     OVLA_CHECK_LAUNCH("ovla_gemm_bf16(w4 hybrid reduce)");
   } else if (splits > 1) {
     const int64_t quads = (int64_t)p.M * (p.N / 4);
@@ -1946,7 +2079,10 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     // ... and on the 4-wave 256x256 config (one head per wave slab, any M)
     const bool fused18 = (tile == 18 || tile == 118) && p.split_k <= 1 && rope_plain && (p.N % 128) == 0 && (a->rope_cols % 128) == 0 &&
                          (((uintptr_t)a->rope_cos | (uintptr_t)a->rope_sin | (uintptr_t)a->C) & 15) == 0 && (a->ldc % 8) == 0;
-    const bool fused = ((tile == 16 || tile == 116) && p.split_k <= 1) || fused17 || fused1 || fused18;
+    // ... and on the 4-wave 128x256 config (two heads per column tile, the RoPE column map; no K-extension)
+    const bool fused22 = (tile == 22 || tile == 122) && p.split_k <= 1 && rope_plain && p.K2 == 0 && (p.N % 256) == 0 && (a->rope_cols % 128) == 0 &&
+                         (((uintptr_t)a->rope_cos | (uintptr_t)a->rope_sin | (uintptr_t)a->C) & 15) == 0 && (a->ldc % 8) == 0;
+    const bool fused = ((tile == 16 || tile == 116) && p.split_k <= 1) || fused17 || fused1 || fused18 || fused22;
     if (fused) {
       p.rope_cos = (const bf16_bits*)a->rope_cos; p.rope_sin = (const bf16_bits*)a->rope_sin;
     } else {
@@ -1988,6 +2124,18 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
         case 64: return launch_w4<2>(p, stream, wsb, hy);
         case 96: return launch_w4<3>(p, stream, wsb, hy);
         default: ovla_set_error("ovla_gemm_bf16: the 4-wave 256x256 config takes a K-extension of 0, 32, 64 or 96 columns, not %d", p.K2); return OVLA_EINVAL;
+      }
+    }
+    case 22: case 122: {   // 128x256 tile on 1 x 4 waves of 128x64, the same hand-scheduled loop (batch-1 shapes: M = 608 = 4.75 row tiles)
+      const bool hy = hybrid || tile == 122;
+      if (p.rope_cos) {   // the RoPE column map (only without a K-extension: the merged / adapter-free decoder of the batch-1 chunk)
+        if (p.K2 != 0) { ovla_set_error("ovla_gemm_bf16: the 128x256 config fuses RoPE only without a K-extension"); return OVLA_EINVAL; }
+        return launch_w4<0, 0, 4, true>(p, stream, wsb, hy);
+      }
+      switch (p.K2) {
+        case 0: return launch_w4<0, 0, 4>(p, stream, wsb, hy);
+        case 32: return launch_w4<1, 0, 4>(p, stream, wsb, hy);
+        default: ovla_set_error("ovla_gemm_bf16: the 4-wave 128x256 config takes a K-extension of 0 or 32 columns, not %d", p.K2); return OVLA_EINVAL;
       }
     }
 #ifdef OVLA_GEMM_ABLATE

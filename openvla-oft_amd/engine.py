@@ -53,6 +53,8 @@ _FUSE_HEAD = {"0": False, "1": True}.get(os.environ.get("OVLA_FUSE_HEAD", "auto"
 _ASYNC_UPLOAD = os.environ.get("OVLA_ASYNC_UPLOAD", "1") != "0"
 # OVLA_FOLD_RMSNORM=0: keep the decoder's RMSNorms as their own launches on the merged inference path (A/B switch of LlamaStack.fold_norms).
 _FOLD_RMSNORM = os.environ.get("OVLA_FOLD_RMSNORM", "1") != "0"
+# OVLA_INFER_W4=0: the folded inference path's projections take the planner's tile instead of the 4-wave 128x256 configuration (A/B switch of LlamaStack._infer_tile)
+_INFER_W4 = os.environ.get("OVLA_INFER_W4", "1") != "0"
 # OVLA_LORA_BWD=1: the LoRA backward's dt and dB from ONE pass over dy (csrc/lora_bwd.hip) instead of a skinny NT GEMM (dt) + TN GEMMs (dB, dA).
 # Built, parity-tested and measured in round 3 (tools/lora_bwd_bench.py, cold operands, M = 4864): 293.6 vs 272.4 us per decoder layer for the
 # three-kernel path -- reading dy once saves 0.4 GB per layer, but a 2-D (rows x 256-column) decomposition pays it back as fp32 partial-dt slabs
@@ -529,12 +531,20 @@ class LlamaStack:
         self.folded = True
         self._fold_plan = {}
 
+    def _infer_tile(self, M: int) -> int:
+        """Tile configuration of the folded inference path's four projections.  A few hundred rows (the batch-1 chunk: M = 608 = 4.75 row tiles of 128): the
+        4-wave 128x256 configuration with the hand-scheduled K loop (ovla.h tile 122: -9...-16 % per projection on cold weights, tools/cold_gemm_probe.py);
+        otherwise 0 = the planner's choice.  OVLA_INFER_W4=0 switches it off."""
+        D, F = self.cfg.llm_dim, self.cfg.llm_ff
+        return 122 if _INFER_W4 and 256 < M <= 1024 and D % 256 == 0 and F % 128 == 0 and D <= 4096 and self.hd == 128 else 0
+
     def _fold_ok(self, M: int) -> bool:
-        """The fold runs in the 128x128 GEMM configuration only (ovla.h): usable when all four projections of an M-row forward resolve to it."""
+        """The fold runs in the 128x128 and the 4-wave 128x256 GEMM configurations only (ovla.h): usable when all four projections of an M-row forward
+        resolve to the former or take the latter."""
         ok = self._fold_plan.get(M)
         if ok is None:
             D, F = self.cfg.llm_dim, self.cfg.llm_ff
-            ok = D % 512 == 0 and self.hd == 128 and all(ops.gemm_plan(M, n, k)[0] == 1 for n, k in ((3 * D, D), (D, D), (2 * F, D), (D, F)))
+            ok = D % 512 == 0 and self.hd == 128 and (self._infer_tile(M) == 122 or all(ops.gemm_plan(M, n, k)[0] == 1 for n, k in ((3 * D, D), (D, D), (2 * F, D), (D, F))))
             self._fold_plan[M] = ok
         return ok
 
@@ -560,13 +570,15 @@ class LlamaStack:
         M = x.shape[0]
         fold = (not train) and getattr(self, "folded", False) and _FOLD_RMSNORM and self._fold_ok(M)
         part = rbuf = None
+        itile = 0
         if fold:   # sums of squares of the first layer's input rows; every later layer's come out of the down projection's epilogue
             part = ops.row_sumsq(x)
             rbuf = torch.empty(M, dtype=F32, device=x.device)
+            itile = self._infer_tile(M)
         for li, l in enumerate(self.layers):
             last_sel = sel is not None and li == len(self.layers) - 1
             if fold:   # RMSNorm + RoPE + q|k|v in ONE launch: rstd from `part`, folded weight, rotation in the epilogue
-                qkv = ops.gemm(x, l["qkv_n"], rope=(cos, sin, S, 2 * D), rowscale=(part, cfg.rms_eps, rbuf))
+                qkv = ops.gemm(x, l["qkv_n"], rope=(cos, sin, S, 2 * D), rowscale=(part, cfg.rms_eps, rbuf), tile=itile)
                 s_qkv = r1 = None
             else:
                 h1, _, r1 = ops.norm_fwd(x, l["n1"], eps=cfg.rms_eps, rms=True, save_stats=train)
@@ -578,11 +590,11 @@ class LlamaStack:
             o, lse = ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, S, H, hd, kv_len=kv_len, causal=causal)
             if fold and not last_sel:
                 part2 = torch.empty((M, D // 64), dtype=F32, device=x.device)
-                x2 = ops.gemm(o, l["o"].W, residual=x, rowsq_out=part2)
-                gu = ops.gemm(x2, l["gu_n"], rowscale=(part2, cfg.rms_eps, rbuf))
+                x2 = ops.gemm(o, l["o"].W, residual=x, rowsq_out=part2, tile=itile)
+                gu = ops.gemm(x2, l["gu_n"], rowscale=(part2, cfg.rms_eps, rbuf), tile=itile)
                 hm = ops.swiglu_fwd(gu)
                 part = torch.empty((M, D // 64), dtype=F32, device=x.device)
-                x = ops.gemm(hm, l["down"].W, residual=x2, rowsq_out=part)
+                x = ops.gemm(hm, l["down"].W, residual=x2, rowsq_out=part, tile=itile)
                 continue
             if last_sel:
                 x2, s_o = l["o"].fwd(ops.gather_rows(o, sel, D), residual=ops.gather_rows(x, sel, D))

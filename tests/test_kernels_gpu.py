@@ -126,12 +126,14 @@ W4_SHAPES = [(128, 128, 64), (1000, 512, 1024), (300, 520, 192), (515, 1152, 115
 
 
 @pytest.mark.parametrize("M,N,K", W4_SHAPES)
-@pytest.mark.parametrize("tile", [18, 118])
+@pytest.mark.parametrize("tile", [18, 118, 22, 122])
 @pytest.mark.parametrize("variant", ["plain", "lora", "lora64", "lora96", "lora3", "bias_res", "gelu_pre", "split2"])
 def test_gemm_w4_config(ops, dev, M, N, K, tile, variant):
     """The 4-wave 256x256 configuration (tiles 18 / 118 = with the hybrid remainder schedule; hand-scheduled inline-asm K loop, LoRA K-extension as a
     prologue, read-back epilogues) against torch fp32 on the same bf16 operands: odd and even K-tile counts, edge tiles, every epilogue path, split-K."""
     torch.manual_seed(M + N + K + len(variant))
+    if tile in (22, 122) and variant in ("lora64", "lora96"):
+        pytest.skip("the 128x256 configuration takes a K-extension of 0 or 32 columns")
     a, b = rnd(M, K, dev=dev, scale=0.5), rnd(N, K, dev=dev, scale=0.1)
     ref = a.float() @ b.float().T
     kw = {}
@@ -673,6 +675,21 @@ def test_gemm_rope_epilogue(ops, dev, M, S, tile):
     assert torch.equal(got, ref), f"{(got != ref).sum().item()} of {ref.numel()} differ"
 
 
+@pytest.mark.parametrize("M,S,tile", [(608, 608, 22), (608, 608, 122), (700, 100, 22), (1216, 304, 122), (4864, 608, 122)])
+def test_gemm_rope_epilogue_128x256(ops, dev, M, S, tile):
+    """RoPE in the epilogue of the 4-wave 128x256 configuration (its column map for RoPE launches; no K-extension: the merged decoder of the batch-1 chunk)
+    == plain GEMM of the same configuration followed by the separate RoPE pass, bit for bit.  3 q | 3 k | 2 v heads of 128: q | k rotated, v untouched."""
+    torch.manual_seed(M + tile)
+    hd, K = 128, 512
+    N = 8 * hd
+    a, b = rnd(M, K, dev=dev, scale=0.5), rnd(N, K, dev=dev, scale=0.1)
+    cos, sin = ops.rope_table(S + 3, hd, 10000.0, dev)
+    ref = ops.gemm(a, b, tile=tile)
+    ops.rope_(ref, S, 6, hd, cos, sin)
+    got = ops.gemm(a, b, rope=(cos, sin, S, 6 * hd), tile=tile)
+    assert torch.equal(got, ref), f"{(got != ref).sum().item()} of {ref.numel()} differ"
+
+
 @pytest.mark.parametrize("rows,vocab,ld", [(171, 32064, 32064), (5, 1000, 1008), (64, 257, 264)])
 def test_token_ce(ops, dev, rows, vocab, ld):
     """ovla_token_ce == torch cross entropy on the fp32-upcast bf16 logits (per-row loss, argmax, gradient), also in place."""
@@ -791,9 +808,10 @@ def test_lora_bwd_one_pass(ops, dev, M, gn, G):
         assert (dt.float() - dt_old.float()).abs().max().item() <= 2.0 ** -7 * dt_old.float().abs().max().item()
 
 
-@pytest.mark.parametrize("M,N,K,tile,rope", [(608, 1024, 512, 1, False), (608, 768, 1024, 1, True), (1000, 1024, 512, 101, False), (300, 640, 512, 101, True)])
+@pytest.mark.parametrize("M,N,K,tile,rope", [(608, 1024, 512, 1, False), (608, 768, 1024, 1, True), (1000, 1024, 512, 101, False), (300, 640, 512, 101, True),
+                                             (608, 1024, 512, 22, False), (608, 768, 1024, 22, True), (1000, 1024, 512, 122, False), (300, 768, 512, 122, True), (608, 1280, 4096, 22, True)])
 def test_gemm_rmsnorm_fold(ops, dev, M, N, K, tile, rope):
-    """RMSNorm folded around the 128x128 GEMM (ovla_gemm_args.rowsq_out / rowscale_part; LlamaStack.fold_norms): the producer's epilogue writes the
+    """RMSNorm folded around the 128x128 GEMM and the 4-wave 128x256 one (tiles 22 / 122) (ovla_gemm_args.rowsq_out / rowscale_part; LlamaStack.fold_norms): the producer's epilogue writes the
     sums of squares of its bf16 output's 64-column groups; the consumer scales its accumulator by rstd[m] = rsqrt(sum / K + eps) before the
     (RoPE) epilogue -- against torch fp32 on the same bf16 operands, interior and edge row tiles, in-kernel epilogue and hybrid-remainder reduce,
     and bit-reproducible between runs (slots are summed in a fixed order)."""

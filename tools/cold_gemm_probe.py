@@ -9,7 +9,7 @@ dev = torch.device("cuda:0")
 M, D, F, L = 608, 4096, 11008, 8
 g = torch.Generator(device="cpu").manual_seed(0)
 shapes = dict(qkv=(3 * D, D), o=(D, D), gate_up=(2 * F, D), down=(D, F))
-cfgs = [(0, 1), (101, 1), (1, 3), (118, 1), (117, 1), (18, 2), (18, 3)] if "quick" in sys.argv else [(0, 1), (1, 1), (101, 1), (14, 1), (14, 2), (14, 3), (17, 1), (117, 1), (20, 1), (21, 1), (10, 1), (15, 1), (1, 2), (1, 3), (2, 1), (102, 1)]
+cfgs = [(0, 1), (101, 1), (1, 3), (122, 1), (22, 1), (22, 2), (22, 3), (118, 1)] if "quick" in sys.argv else [(0, 1), (1, 1), (101, 1), (14, 1), (14, 2), (14, 3), (17, 1), (117, 1), (20, 1), (21, 1), (10, 1), (15, 1), (1, 2), (1, 3), (2, 1), (102, 1)]
 for name, (N, K) in shapes.items():
     Ws = [(torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16).to(dev) for _ in range(L)]
     x = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(dev)
