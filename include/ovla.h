@@ -64,7 +64,11 @@ int ovla_check_device(int device);
  * Requirements: K % 8 == 0, K2 % 8 == 0, N % 8 == 0, ld* % 8 == 0, 16-byte aligned base pointers.
  * split_k > 1 needs `workspace` of ovla_gemm_workspace_bytes() bytes.
  */
-enum { OVLA_ACT_NONE = 0, OVLA_ACT_GELU = 1, OVLA_ACT_RELU = 2, OVLA_ACT_SILU = 3, OVLA_ACT_GELU_TANH = 4 };
+enum { OVLA_ACT_NONE = 0, OVLA_ACT_GELU = 1, OVLA_ACT_RELU = 2, OVLA_ACT_SILU = 3, OVLA_ACT_GELU_TANH = 4,
+       /* ovla_gemm_bf16 only, tile 22 / 122 only: B = [gate; up] stacked ([N = 2 F, K], F % 128 == 0), C is [M, F] = bf16(bf16(silu(g)) * u) with g | u the
+        * bf16-rounded projection outputs -- HF LlamaMLP's act_fn(gate_proj(x)) * up_proj(x) (modeling_llama.py) without the [M, 2 F] intermediate; nothing else
+        * in the epilogue but alpha and the RMSNorm-fold row scale (rowscale_part).  Same bits as ovla_gemm_bf16 + ovla_swiglu_fwd. */
+       OVLA_ACT_SWIGLU = 5 };
 
 typedef struct {
   const void* A; int64_t lda;

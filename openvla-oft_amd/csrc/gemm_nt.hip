@@ -815,7 +815,7 @@ constexpr int w4_newer(int r, bool stage, int NT, int NPR, bool TOPW) {
     if (ev[e] == 100 + r || (r == 8 && ev[e] == 200 + NT - 1)) last = e;
   return n - 1 - last;
 }
-template <int KEXT, int ABL = 0, int WNW = 2, bool RMAP = false>   // WNW = waves along N: 2 -> the 256x256 tile (2 x 2 waves of 128x128), 4 -> a 128x256 tile (1 x 4 waves of 128x64: batch-1 shapes; RMAP: its column map for RoPE launches, below);  KEXT: 32-wide k-steps of the LoRA K-extension (0 .. 3);  ABL: timing-only ablations (OVLA_GEMM_ABLATE builds), bits: 1 = no staging after the prologue, 2 = no fragment reads, 4 = no lgkmcnt waits in the rows, 8 = no vmcnt waits in the rows
+template <int KEXT, int ABL = 0, int WNW = 2, bool RMAP = false, bool GMAP = false>   // GMAP: the SwiGLU pair map of the 128x256 configuration (act = OVLA_ACT_SWIGLU, below);  WNW = waves along N: 2 -> the 256x256 tile (2 x 2 waves of 128x128), 4 -> a 128x256 tile (1 x 4 waves of 128x64: batch-1 shapes; RMAP: its column map for RoPE launches, below);  KEXT: 32-wide k-steps of the LoRA K-extension (0 .. 3);  ABL: timing-only ablations (OVLA_GEMM_ABLATE builds), bits: 1 = no staging after the prologue, 2 = no fragment reads, 4 = no lgkmcnt waits in the rows, 8 = no vmcnt waits in the rows
 __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   constexpr int WMW = 4 / WNW, BM = 128 * WMW, BN = 256, WTM = 128, WTN = BN / WNW, MT = 8, NT = WTN / 16;
   constexpr int PA = BM / 32, PB = BN / 32, NP = PA + PB;   // 1-KiB staging pieces (8 rows x 128 bytes) per wave and K tile: of A, of B, together (16 / 12)
@@ -829,9 +829,13 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   // Column map of the wave's n-tiles.  Plain: wave wn owns columns wn * WTN + 16 j.  RMAP (128x256 configuration, RoPE launches: head_dim 128 = two 64-column
   // wave strips): wave (h = wn >> 1, w2 = wn & 1) takes columns h * 128 + 32 w2 + [0, 32) AND their rotation partners + 64, i.e. tile j sits at
   // 16 (j & 1) + 64 (j >> 1): the partner of a slab column is 32 slab columns away in the same row of the wave's own slab.
-  static_assert(!RMAP || WNW == 4, "the RoPE column map belongs to the 128x256 configuration");
-  const int cb = RMAP ? (wn >> 1) * 128 + (wn & 1) * 32 : wn * WTN;     // first column of the wave inside the tile
-  auto cj = [](int j) constexpr { return RMAP ? 16 * (j & 1) + 64 * (j >> 1) : 16 * j; };   // column of n-tile j relative to cb
+  // GMAP (128x256 configuration, act = OVLA_ACT_SWIGLU: B = [gate; up] stacked, 2 F rows): a workgroup takes 128 gate rows n0 + [0, 128) AND the 128 up rows
+  // F + n0 + [0, 128) as its B tile; wave wn owns gate columns 32 wn + [0, 32) (n-tiles 0, 1) and the SAME up columns (n-tiles 2, 3): its slab row holds 32 gate
+  // values and, 32 slab columns on, their up partners -- silu(g) * u is computed in the read-back and C is [M, F].
+  static_assert(!(RMAP || GMAP) || WNW == 4, "the RoPE and the SwiGLU column maps belong to the 128x256 configuration");
+  static_assert(!(RMAP && GMAP) && (!GMAP || KEXT == 0), "one map at a time; the SwiGLU map has no K-extension");
+  const int cb = RMAP ? (wn >> 1) * 128 + (wn & 1) * 32 : GMAP ? wn * 32 : wn * WTN;     // first column of the wave inside the tile
+  auto cj = [](int j) constexpr { return RMAP ? 16 * (j & 1) + 64 * (j >> 1) : GMAP ? 16 * (j & 1) + 128 * (j >> 1) : 16 * j; };   // column (B-tile row) of n-tile j relative to cb
   auto scol = [](int sc) constexpr { return RMAP ? (sc & 31) + 64 * (sc >> 5) : sc; };      // column (relative to cb) of slab column sc = 16 j + c
   OVLA_STAMP(0);
 
@@ -862,7 +866,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   const int in_group = t_mn - gid * group_sz;
   const int tm = first_m + in_group % gm;
   const int tn = in_group / gm;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BM, n0 = tn * (GMAP ? 128 : BN);   // (GMAP: 128 output = gate columns per tile; the host sets tiles_n = F / 128)
 
   const int T = p.T1;
   int t_begin = 0, t_end = T;
@@ -889,6 +893,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     int gb = n0 + (wave * PB + i) * 8 + (lane >> 3);
+    if constexpr (GMAP) { const int br = (wave * PB + i) * 8 + (lane >> 3); gb = br < 128 ? n0 + br : (p.N >> 1) + n0 + (br - 128); }   // gate rows, then the up rows F + the same
     gb = gb < p.N - 1 ? gb : p.N - 1;
     offB[i] = (uint32_t)(((int64_t)gb * p.ldb + (lane & 7) * 8) * 2);
   }
@@ -1169,6 +1174,35 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
           o[e] = (short)f2bf(upper ? bfround(x * cc) + bfround(y * sv) : bfround(x * cc) + bfround(-y * sv));
         }
         if (m < p.M && n < p.N) *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    });
+    return;
+  }
+  if constexpr (GMAP) {   // SwiGLU in the read-back (swiglu_fwd_kernel's arithmetic on the bf16-rounded projection outputs): h = bf16(bf16(silu(g)) * u)
+    static_for<MT / 2>([&](auto rd_tag) {
+      constexpr int rd = decltype(rd_tag)::value;
+      to_slab(rd_tag);
+      f32x4 gl[2], gh[2], ul[2], uh[2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {   // 32 rows x 4 output octets = 128 items = 2 steps
+        const int idx = st * 64 + lane, row = idx >> 2, c8 = idx & 3;
+        const float* gs = slab + row * LDSW + c8 * 8;
+        gl[st] = *reinterpret_cast<const f32x4*>(gs); gh[st] = *reinterpret_cast<const f32x4*>(gs + 4);
+        ul[st] = *reinterpret_cast<const f32x4*>(gs + 32); uh[st] = *reinterpret_cast<const f32x4*>(gs + 36);
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const int idx = st * 64 + lane, row = idx >> 2, c8 = idx & 3;
+        const int m = mbase + rd * 32 + row, n = n0 + wn * 32 + c8 * 8;
+        const float ra = p.alpha * (rowscale ? s_rstd[rd * 32 + row] : 1.f);
+        bf16x8_bits o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gg = bfround((e < 4 ? gl[st][e] : gh[st][e - 4]) * ra), uu = bfround((e < 4 ? ul[st][e] : uh[st][e - 4]) * ra);
+          o[e] = (short)f2bf(bfround(silu(gg)) * uu);
+        }
+        if (m < p.M && n < (p.N >> 1)) *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     });
@@ -1874,7 +1908,7 @@ int launch_pipe(GemmParams& p, hipStream_t stream) {
   return OVLA_OK;
 }
 
-template <int KEXT, int ABL = 0, int WNW = 2, bool RMAP = false>
+template <int KEXT, int ABL = 0, int WNW = 2, bool RMAP = false, bool GMAP = false>
 int launch_w4(GemmParams& p, hipStream_t stream, int64_t ws_bytes, bool hybrid) {
   constexpr int BM = 128 * (4 / WNW), BN = 256;
   if (p.K % BK != 0 || p.K2 != 32 * KEXT || !p.fast_addr || p.a_group_n > 0 || (p.k2_group_n > 0 && (p.k2_group_n % 256) != 0)) {
@@ -1886,10 +1920,17 @@ int launch_w4(GemmParams& p, hipStream_t stream, int64_t ws_bytes, bool hybrid) 
     return OVLA_EINVAL;
   }
   p.tiles_m = cdiv(p.M, BM);
-  p.tiles_n = cdiv(p.N, BN);
+  p.tiles_n = GMAP ? (p.N / 2) / 128 : cdiv(p.N, BN);
+  if (GMAP) {
+    if ((p.N % 256) != 0 || p.split_k > 1 || p.rowsq_out || p.bias || p.residual || p.colscale || p.Cpre || p.film_gamma || p.dact_src || p.rope_cos) {
+      ovla_set_error("ovla_gemm_bf16: act = OVLA_ACT_SWIGLU needs N = 2 F with F %% 128 == 0 and nothing else in the epilogue but alpha / the RMSNorm-fold row scale");
+      return OVLA_EINVAL;
+    }
+    hybrid = false;   // (the remainder reduce knows nothing of gate | up pairs: whole tiles only)
+  }
   const int splits = p.split_k > 1 ? p.split_k : 1;
   const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16_bits) + (WNW == 4 ? 128 * sizeof(float) : 0);   // + s_rstd of the RMSNorm fold
-  auto kern = gemm_nt_w4_kernel<KEXT, ABL, WNW, RMAP>;
+  auto kern = gemm_nt_w4_kernel<KEXT, ABL, WNW, RMAP, GMAP>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1955,7 +1996,7 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   OVLA_REQUIRE(a->A && a->B && a->C, "ovla_gemm_bf16: null A/B/C");
   OVLA_REQUIRE((a->K % 8) == 0 && (a->N % 8) == 0, "ovla_gemm_bf16: K=%d and N=%d must be multiples of 8", a->K, a->N);
   OVLA_REQUIRE((a->lda % 8) == 0 && (a->ldb % 8) == 0 && (a->ldc % 4) == 0, "ovla_gemm_bf16: lda/ldb must be multiples of 8, ldc of 4");
-  OVLA_REQUIRE(a->lda >= a->K && a->ldb >= a->K && a->ldc >= a->N, "ovla_gemm_bf16: leading dimension smaller than extent");
+  OVLA_REQUIRE(a->lda >= a->K && a->ldb >= a->K && a->ldc >= (a->act == OVLA_ACT_SWIGLU ? a->N / 2 : a->N), "ovla_gemm_bf16: leading dimension smaller than extent");
   OVLA_REQUIRE(aligned16(a->A) && aligned16(a->B) && (((uintptr_t)a->C) & 7) == 0, "ovla_gemm_bf16: A/B need 16-byte, C 8-byte alignment");
   if (a->a_group_n > 0) {
     OVLA_REQUIRE(a->K2 <= 0 && (a->N % a->a_group_n) == 0 && (a->a_group_n == 32 || a->a_group_n % 128 == 0) && a->lda >= (int64_t)(a->N / a->a_group_n) * a->K,
@@ -2031,6 +2072,8 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
 
   int tile = a->tile % 1000;
   const int64_t wsb = a->workspace ? a->workspace_bytes : 0;
+  if (a->act == OVLA_ACT_SWIGLU)
+    OVLA_REQUIRE((tile == 22 || tile == 122) && a->ldc >= a->N / 2, "ovla_gemm_bf16: act = OVLA_ACT_SWIGLU (C [M, N / 2] = silu(gate) * up of the stacked [gate; up] projection) runs on tile 22 / 122 only");
   bool hybrid = false;
   if (tile == 0) {
     // auto schedule.  Skinny outputs (LoRA t / dt, N <= 128) and small M (action head) are HBM-bound weight/activation
@@ -2128,6 +2171,10 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     }
     case 22: case 122: {   // 128x256 tile on 1 x 4 waves of 128x64, the same hand-scheduled loop (batch-1 shapes: M = 608 = 4.75 row tiles)
       const bool hy = hybrid || tile == 122;
+      if (p.act == OVLA_ACT_SWIGLU) {   // the SwiGLU pair map (no K-extension)
+        if (p.K2 != 0) { ovla_set_error("ovla_gemm_bf16: act = OVLA_ACT_SWIGLU takes no K-extension"); return OVLA_EINVAL; }
+        return launch_w4<0, 0, 4, false, true>(p, stream, wsb, false);
+      }
       if (p.rope_cos) {   // the RoPE column map (only without a K-extension: the merged / adapter-free decoder of the batch-1 chunk)
         if (p.K2 != 0) { ovla_set_error("ovla_gemm_bf16: the 128x256 config fuses RoPE only without a K-extension"); return OVLA_EINVAL; }
         return launch_w4<0, 0, 4, true>(p, stream, wsb, hy);

@@ -591,8 +591,11 @@ class LlamaStack:
             if fold and not last_sel:
                 part2 = torch.empty((M, D // 64), dtype=F32, device=x.device)
                 x2 = ops.gemm(o, l["o"].W, residual=x, rowsq_out=part2, tile=itile)
-                gu = ops.gemm(x2, l["gu_n"], rowscale=(part2, cfg.rms_eps, rbuf), tile=itile)
-                hm = ops.swiglu_fwd(gu)
+                if itile == 122:   # RMSNorm + gate|up + SwiGLU in ONE launch (ovla.h: OVLA_ACT_SWIGLU on the 128x256 configuration): the [M, 2F] intermediate never exists
+                    hm = ops.gemm(x2, l["gu_n"], rowscale=(part2, cfg.rms_eps, rbuf), tile=22, act=ops.ACT_SWIGLU)
+                else:
+                    gu = ops.gemm(x2, l["gu_n"], rowscale=(part2, cfg.rms_eps, rbuf), tile=itile)
+                    hm = ops.swiglu_fwd(gu)
                 part = torch.empty((M, D // 64), dtype=F32, device=x.device)
                 x = ops.gemm(hm, l["down"].W, residual=x2, rowsq_out=part, tile=itile)
                 continue

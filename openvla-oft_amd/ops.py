@@ -9,7 +9,7 @@ import torch
 from . import _lib
 from ._lib import STRUCTS
 
-ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU, ACT_GELU_TANH = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU, ACT_GELU_TANH, ACT_SWIGLU = 0, 1, 2, 3, 4, 5
 BF16 = torch.bfloat16
 
 # bench.py sets this to a list to time individual launches with HIP events on the launch stream:
@@ -103,7 +103,7 @@ def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=Non
         assert a.shape[1] == (N // a_group_n) * K, f"gemm(block-diagonal): {a.shape} vs {b.shape}"
     assert b.shape[1] == K, f"gemm: K mismatch {a.shape} x {b.shape}"
     assert a.stride(1) == 1 and b.stride(1) == 1
-    out_cols = 2 * N if (dact is not None and dact[0] == "swiglu") else N
+    out_cols = 2 * N if (dact is not None and dact[0] == "swiglu") else (N // 2 if act == ACT_SWIGLU else N)   # ACT_SWIGLU: b = [gate; up], out = silu(gate) * up
     if out is None:
         out = torch.empty((M, out_cols), dtype=BF16, device=a.device)
     assert out.shape == (M, out_cols) and out.stride(1) == 1

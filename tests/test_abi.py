@@ -147,7 +147,7 @@ def test_w4_gemm_loop_is_what_the_source_wrote(libmod, tmp_path):
             ends = [max(k for k in range(b, nxt) if ops[k].startswith("v_mfma")) for b, nxt in zip(body_starts, body_starts[1:] + [last_mfma + 1])]
             loop = [op for b, e in zip(body_starts, ends) for op in ops[b:e + 1]]
             c = lambda pre: sum(1 for op in loop if op.startswith(pre))
-            wide = "Li2ELb" in m.group(1)        # <KEXT, ABL, WNW = 2, RMAP>: the 256x256 tile (128x128 per wave); WNW = 4: 128x256 (128x64 per wave)
+            wide = "Li2ELb" in m.group(1)        # <KEXT, ABL, WNW = 2, RMAP, GMAP>: the 256x256 tile (128x128 per wave); WNW = 4: 128x256 (128x64 per wave)
             nt, npieces = (8, 16) if wide else (4, 12)
             assert c("v_mfma") == 3 * 16 * nt + nt, (m.group(1), c("v_mfma"))                      # + the last deferred row
             assert c("ds_read_b128") == 3 * (16 + 2 * nt) and c("ds_write_b128") == 2 * npieces and c("global_load_dwordx4") == 2 * npieces, (m.group(1), c("ds_read_b128"), c("ds_write_b128"), c("global_load_dwordx4"))
@@ -175,4 +175,4 @@ def test_w4_gemm_loop_is_what_the_source_wrote(libmod, tmp_path):
                         if prev.startswith("v_") and not prev.startswith("v_mfma"):
                             dst = regs(prev.split(None, 1)[1].split(",")[0].strip())
                             assert not (dst & src), f"{m.group(1)}: `{prev}` writes a source of `{line}` {back} instruction(s) before it"
-    assert seen == 7, f"{seen} gemm_nt_w4_kernel instantiations found in the shipped library (256x256: K-extensions of 0 / 32 / 64 / 96 columns; 128x256: 0, 32, 0 with the RoPE column map)"
+    assert seen == 8, f"{seen} gemm_nt_w4_kernel instantiations found in the shipped library (256x256: K-extensions of 0 / 32 / 64 / 96 columns; 128x256: 0, 32, 0 with the RoPE column map, 0 with the SwiGLU pair map)"

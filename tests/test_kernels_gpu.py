@@ -675,6 +675,25 @@ def test_gemm_rope_epilogue(ops, dev, M, S, tile):
     assert torch.equal(got, ref), f"{(got != ref).sum().item()} of {ref.numel()} differ"
 
 
+@pytest.mark.parametrize("M,F,K,fold", [(608, 1408, 512, False), (608, 1408, 1024, True), (300, 256, 4096, True), (1000, 640, 192, False), (128, 128, 64, False)])
+def test_gemm_swiglu_pair_epilogue(ops, dev, M, F, K, fold):
+    """act = OVLA_ACT_SWIGLU on the 4-wave 128x256 configuration: the stacked [gate; up] projection with silu(gate) * up in the read-back (its column map puts
+    a gate value and its up partner into the same slab row) == the projection followed by ovla_swiglu_fwd, bit for bit -- with and without the RMSNorm-fold
+    row scale, edge row tiles included."""
+    torch.manual_seed(M + F + K)
+    x, w = rnd(M, K, dev=dev, scale=0.5), rnd(2 * F, K, dev=dev, scale=0.1)
+    kw = {}
+    if fold:
+        part = (x.float().view(M, K // 64, 64).pow(2).sum(-1)).contiguous()
+        kw["rowscale"] = (part, 1e-5, torch.empty(M, device=dev))
+    gu = ops.gemm(x, w, tile=22, **kw)
+    ref = ops.swiglu_fwd(gu)
+    got = ops.gemm(x, w, tile=22, act=ops.ACT_SWIGLU, **kw)
+    assert got.shape == (M, F) and torch.equal(got, ref), f"{(got != ref).sum().item()} of {ref.numel()} differ"
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, w, tile=17, act=ops.ACT_SWIGLU)
+
+
 @pytest.mark.parametrize("M,S,tile", [(608, 608, 22), (608, 608, 122), (700, 100, 22), (1216, 304, 122), (4864, 608, 122)])
 def test_gemm_rope_epilogue_128x256(ops, dev, M, S, tile):
     """RoPE in the epilogue of the 4-wave 128x256 configuration (its column map for RoPE launches; no K-extension: the merged decoder of the batch-1 chunk)
