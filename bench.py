@@ -416,9 +416,9 @@ def main():
             d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fl
         ops.PROFILE = None
         # the dominant kernel = the gemm_nt instance with the most time in the step (ops._gemm_family names the instance each
-        # launch runs: t17 = gemm_nt_kernel<256,256,2,4>, t18k<KEXT> = its 4-wave configuration gemm_nt_w4_kernel<KEXT, 0, 2, false> (KEXT = LoRA K-extension / 32), t1 = <128,128,2,2>, t2 = <64,128,1,4>, t5 = <128,32,4,1>; a launch's
+        # launch runs: t17 = gemm_nt_kernel<256,256,2,4>, t18k<KEXT> = its 4-wave configuration gemm_nt_w4_kernel<KEXT, 0, 2, false, false> (KEXT = LoRA K-extension / 32), t1 = <128,128,2,2>, t2 = <64,128,1,4>, t5 = <128,32,4,1>; a launch's
         # events also cover its split-K / hybrid reduce kernel)
-        inst = {"gemm_nt_t17": "gemm_nt_kernel<256,256,2,4>", "gemm_nt_t18k0": "gemm_nt_w4_kernel<0, 0, 2, false>", "gemm_nt_t18k1": "gemm_nt_w4_kernel<1, 0, 2, false>", "gemm_nt_t18k2": "gemm_nt_w4_kernel<2, 0, 2, false>", "gemm_nt_t18k3": "gemm_nt_w4_kernel<3, 0, 2, false>", "gemm_nt_t1": "gemm_nt_kernel<128,128,2,2>",
+        inst = {"gemm_nt_t17": "gemm_nt_kernel<256,256,2,4>", "gemm_nt_t18k0": "gemm_nt_w4_kernel<0, 0, 2, false, false>", "gemm_nt_t18k1": "gemm_nt_w4_kernel<1, 0, 2, false, false>", "gemm_nt_t18k2": "gemm_nt_w4_kernel<2, 0, 2, false, false>", "gemm_nt_t18k3": "gemm_nt_w4_kernel<3, 0, 2, false, false>", "gemm_nt_t1": "gemm_nt_kernel<128,128,2,2>",
                 "gemm_nt_t2": "gemm_nt_kernel<64,128,1,4>", "gemm_nt_t5": "gemm_nt_kernel<128,32,4,1>", "gemm_nt_t6": "gemm_skinny_kernel<2>"}
         gemms = {k: v for k, v in fam.items() if k.startswith("gemm_nt")}
         dom = max(gemms, key=lambda k: gemms[k][1])
@@ -503,7 +503,7 @@ def main():
         igemm = {k: v for k, v in ifam.items() if k.startswith("gemm_nt")}
         idom = max(igemm, key=lambda k: igemm[k][1])
         inst1 = {"gemm_nt_t17": "gemm_nt_kernel<256,256,2,4>", "gemm_nt_t1": "gemm_nt_kernel<128,128,2,2>", "gemm_nt_t2": "gemm_nt_kernel<64,128,1,4>",
-                 "gemm_nt_t5": "gemm_nt_kernel<128,32,4,1>", "gemm_nt_t22": "gemm_nt_w4_kernel<0, 0, 4, false | true> (the 128x256 tile on 4 waves; true = with the RoPE column map)"}
+                 "gemm_nt_t5": "gemm_nt_kernel<128,32,4,1>", "gemm_nt_t22": "gemm_nt_w4_kernel<0, 0, 4, RMAP, GMAP> (the 128x256 tile on 4 waves: plain / with the RoPE column map / with the SwiGLU pair map)"}
         infer_roofline = {
             "mfma": {"flops_per_chunk": flp1["fwd"], "achieved": flp1["fwd"] / (ms_graph * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                      "frac": flp1["fwd"] / (ms_graph * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "floor_ms": flp1["fwd"] / (PEAK_BF16_TFLOPS * 1e12) * 1e3},
