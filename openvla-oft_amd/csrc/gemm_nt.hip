@@ -829,13 +829,15 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   // Column map of the wave's n-tiles.  Plain: wave wn owns columns wn * WTN + 16 j.  RMAP (128x256 configuration, RoPE launches: head_dim 128 = two 64-column
   // wave strips): wave (h = wn >> 1, w2 = wn & 1) takes columns h * 128 + 32 w2 + [0, 32) AND their rotation partners + 64, i.e. tile j sits at
   // 16 (j & 1) + 64 (j >> 1): the partner of a slab column is 32 slab columns away in the same row of the wave's own slab.
-  // GMAP (128x256 configuration, act = OVLA_ACT_SWIGLU: B = [gate; up] stacked, 2 F rows): a workgroup takes 128 gate rows n0 + [0, 128) AND the 128 up rows
-  // F + n0 + [0, 128) as its B tile; wave wn owns gate columns 32 wn + [0, 32) (n-tiles 0, 1) and the SAME up columns (n-tiles 2, 3): its slab row holds 32 gate
-  // values and, 32 slab columns on, their up partners -- silu(g) * u is computed in the read-back and C is [M, F].
-  static_assert(!(RMAP || GMAP) || WNW == 4, "the RoPE and the SwiGLU column maps belong to the 128x256 configuration");
-  static_assert(!(RMAP && GMAP) && (!GMAP || KEXT == 0), "one map at a time; the SwiGLU map has no K-extension");
-  const int cb = RMAP ? (wn >> 1) * 128 + (wn & 1) * 32 : GMAP ? wn * 32 : wn * WTN;     // first column of the wave inside the tile
-  auto cj = [](int j) constexpr { return RMAP ? 16 * (j & 1) + 64 * (j >> 1) : GMAP ? 16 * (j & 1) + 128 * (j >> 1) : 16 * j; };   // column (B-tile row) of n-tile j relative to cb
+  // GMAP (act = OVLA_ACT_SWIGLU: B = [gate; up] stacked, 2 F rows): a workgroup takes 128 gate rows n0 + [0, 128) AND the 128 up rows F + n0 + [0, 128) as its
+  // B tile; wave wn owns gate columns (WTN / 2) wn + [0, WTN / 2) (the first half of its n-tiles) and the SAME up columns (the second half): its slab row holds
+  // WTN / 2 gate values and, WTN / 2 slab columns on, their up partners -- silu(g) * u is computed in the read-back and C is [M, F] (C_pre, if given, receives
+  // the [M, 2 F] projection output itself: the fine-tune step keeps it for the backward).
+  static_assert(!RMAP || WNW == 4, "the RoPE column map belongs to the 128x256 configuration");
+  static_assert(!(RMAP && GMAP) && (!GMAP || KEXT <= 1), "one map at a time; the SwiGLU map takes a K-extension of 0 or 32 columns");
+  constexpr int NH = NT / 2;
+  const int cb = RMAP ? (wn >> 1) * 128 + (wn & 1) * 32 : GMAP ? wn * (WTN / 2) : wn * WTN;     // first column of the wave inside the tile
+  auto cj = [](int j) constexpr { return RMAP ? 16 * (j & 1) + 64 * (j >> 1) : GMAP ? 16 * (j % NH) + 128 * (j / NH) : 16 * j; };   // column (B-tile row) of n-tile j relative to cb
   auto scol = [](int sc) constexpr { return RMAP ? (sc & 31) + 64 * (sc >> 5) : sc; };      // column (relative to cb) of slab column sc = 16 j + c
   OVLA_STAMP(0);
 
@@ -958,7 +960,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
   OVLA_STAMP(1);
   // (K2 = 32 KEXT, host-checked.  Straight-line code: a branch around asm that updates 64 accumulators makes the compiler merge them through scratch.  Two
   // fragment sets: steps 0 and 1 are requested up front, step 2 into set 0 once step 0's MFMAs have read it.)
-  bf16x8_bits a2f[KEXT > 1 ? 2 : 1][KEXT ? MT : 1], b2f[KEXT > 1 ? 2 : 1][KEXT ? NT : 1];
+  bf16x8_bits a2f[(KEXT > 1 || GMAP) ? 2 : 1][KEXT ? MT : 1], b2f[KEXT > 1 ? 2 : 1][KEXT ? NT : 1];   // (GMAP: a2f[0] / a2f[1] = the gate / the up group's columns of A2)
   const bf16_bits* a2p = nullptr;
   const bf16_bits* b2p = nullptr;
   auto kext_load = [&](auto set_tag, int ks) {
@@ -966,7 +968,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) { int m = m0 + arow + i * 16; m = m < p.M - 1 ? m : p.M - 1; a2f[S][i] = *reinterpret_cast<const bf16x8_bits*>(a2p + (int64_t)m * p.lda2 + ks * 32); }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) { int n = n0 + brow + cj(j); n = n < p.N - 1 ? n : p.N - 1; b2f[S][j] = *reinterpret_cast<const bf16x8_bits*>(b2p + (int64_t)n * p.ldb2 + ks * 32); }
+    for (int j = 0; j < NT; ++j) { int n = n0 + brow + cj(j); if constexpr (GMAP) n = n0 + brow + (cj(j) & 127) + (cj(j) >= 128 ? (p.N >> 1) : 0); n = n < p.N - 1 ? n : p.N - 1; b2f[S][j] = *reinterpret_cast<const bf16x8_bits*>(b2p + (int64_t)n * p.ldb2 + ks * 32); }
   };
   if constexpr (KEXT > 0) {
     const int a2_col0 = p.k2_group_n > 0 ? (n0 / p.k2_group_n) * p.K2 : 0;
@@ -974,6 +976,11 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
     b2p = p.B2 + 8 * cq;
     kext_load(std::integral_constant<int, 0>{}, 0);
     if constexpr (KEXT > 1) kext_load(std::integral_constant<int, 1>{}, 1);
+    if constexpr (GMAP) {   // the up rows' LoRA group (k2_group_n = F for the fused gate | up linear: group 1; ungrouped: the same columns again)
+      const int up_col0 = p.k2_group_n > 0 ? (((p.N >> 1) + n0) / p.k2_group_n) * p.K2 : 0;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) { int m = m0 + arow + i * 16; m = m < p.M - 1 ? m : p.M - 1; a2f[1][i] = *reinterpret_cast<const bf16x8_bits*>(p.A2 + up_col0 + 8 * cq + (int64_t)m * p.lda2); }
+    }
   }
   {
     const char* gA = tile_base(p.A, clampt(t_begin));
@@ -1007,7 +1014,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
       constexpr int st = decltype(s_tag)::value, S = st & 1;
       if (!mine) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) a2f[S][i] = bf16x8_bits{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < MT; ++i) { a2f[S][i] = bf16x8_bits{0, 0, 0, 0, 0, 0, 0, 0}; if constexpr (GMAP) a2f[1][i] = a2f[S][i]; }
       }
       // The compiler may have written a fragment register with a VALU instruction right here (the zeroing above, or a v_mov restoring a register it borrowed
       // -- seen in the listing, and the first MFMA then read the stale value: the hazard recognizer cannot know that the asm below is an MFMA and inserts
@@ -1015,7 +1022,7 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
       asm volatile("s_nop 4");
       static_for<MT * NT>([&](auto e_tag) {
         constexpr int i = decltype(e_tag)::value / NT, j = decltype(e_tag)::value % NT;
-        if constexpr (st == 0) acc[i][j] = w4_mfma0(b2f[S][j], a2f[S][i]);
+        if constexpr (st == 0) acc[i][j] = w4_mfma0(b2f[S][j], a2f[GMAP ? (j < NH ? 0 : 1) : S][i]);
         else acc[i][j] = w4_mfma(acc[i][j], b2f[S][j], a2f[S][i]);
       });
       if constexpr (st + 2 < KEXT) kext_load(std::integral_constant<int, S>{}, st + 2);
@@ -1180,29 +1187,38 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
     return;
   }
   if constexpr (GMAP) {   // SwiGLU in the read-back (swiglu_fwd_kernel's arithmetic on the bf16-rounded projection outputs): h = bf16(bf16(silu(g)) * u)
+    constexpr int HO = OCT / 2, GST = 32 * HO / 64;   // output octets per slab row (gate octet c8 and its up partner HO octets on); read-back steps per round (4 / 2)
+    const int F = p.N >> 1;
     static_for<MT / 2>([&](auto rd_tag) {
       constexpr int rd = decltype(rd_tag)::value;
       to_slab(rd_tag);
-      f32x4 gl[2], gh[2], ul[2], uh[2];
+      f32x4 gl[GST], gh[GST], ul[GST], uh[GST];
 #pragma unroll
-      for (int st = 0; st < 2; ++st) {   // 32 rows x 4 output octets = 128 items = 2 steps
-        const int idx = st * 64 + lane, row = idx >> 2, c8 = idx & 3;
+      for (int st = 0; st < GST; ++st) {
+        const int idx = st * 64 + lane, row = idx / HO, c8 = idx % HO;
         const float* gs = slab + row * LDSW + c8 * 8;
         gl[st] = *reinterpret_cast<const f32x4*>(gs); gh[st] = *reinterpret_cast<const f32x4*>(gs + 4);
-        ul[st] = *reinterpret_cast<const f32x4*>(gs + 32); uh[st] = *reinterpret_cast<const f32x4*>(gs + 36);
+        ul[st] = *reinterpret_cast<const f32x4*>(gs + WTN / 2); uh[st] = *reinterpret_cast<const f32x4*>(gs + WTN / 2 + 4);
       }
 #pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        const int idx = st * 64 + lane, row = idx >> 2, c8 = idx & 3;
-        const int m = mbase + rd * 32 + row, n = n0 + wn * 32 + c8 * 8;
-        const float ra = p.alpha * (rowscale ? s_rstd[rd * 32 + row] : 1.f);
-        bf16x8_bits o;
+      for (int st = 0; st < GST; ++st) {
+        const int idx = st * 64 + lane, row = idx / HO, c8 = idx % HO;
+        const int m = mbase + rd * 32 + row, n = n0 + cb + c8 * 8;
+        float ra = p.alpha;
+        if constexpr (WNW == 4) { if (rowscale) ra *= s_rstd[rd * 32 + row]; }
+        bf16x8_bits o, og, ou;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float gg = bfround((e < 4 ? gl[st][e] : gh[st][e - 4]) * ra), uu = bfround((e < 4 ? ul[st][e] : uh[st][e - 4]) * ra);
-          o[e] = (short)f2bf(bfround(silu(gg)) * uu);
+          og[e] = (short)f2bf((e < 4 ? gl[st][e] : gh[st][e - 4]) * ra); ou[e] = (short)f2bf((e < 4 ? ul[st][e] : uh[st][e - 4]) * ra);
+          o[e] = (short)f2bf(bfround(silu(bf2f((bf16_bits)og[e]))) * bf2f((bf16_bits)ou[e]));
         }
-        if (m < p.M && n < (p.N >> 1)) *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
+        if (m < p.M && n < F) {
+          *reinterpret_cast<bf16x8_bits*>(p.C + (int64_t)m * p.ldc + n) = o;
+          if (p.Cpre) {   // the projection output itself, [M, 2 F] with row stride N
+            *reinterpret_cast<bf16x8_bits*>(p.Cpre + (int64_t)m * p.N + n) = og;
+            *reinterpret_cast<bf16x8_bits*>(p.Cpre + (int64_t)m * p.N + F + n) = ou;
+          }
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     });
@@ -1727,6 +1743,29 @@ OVLA_DEV void hybrid_reduce_quads(const GemmParams& p, int rt, int q0, int qstri
   const float* slab0 = p.ws + (int64_t)rt * p.rem_splits * (BM * BN);
   for (int q = q0; q < BM * BN / 4; q += qstride) {
     const int lm = q / (BN / 4), ln = (q % (BN / 4)) * 4;
+    if (p.act == OVLA_ACT_SWIGLU) {   // SwiGLU pair map (4-wave configs): tile-local columns [0, 128) are gate columns tn * 128 + ln, [128, 256) their up partners
+      if (ln >= 128) continue;
+      const int F = p.N >> 1, mg = m0 + lm, ng = (in_group / gm) * 128 + ln;
+      if (mg >= p.M || ng >= F) continue;
+      f32x4 vg = {0.f, 0.f, 0.f, 0.f}, vu = {0.f, 0.f, 0.f, 0.f};
+      for (int sidx = 0; sidx < p.rem_splits; ++sidx) {
+        vg += *reinterpret_cast<const f32x4*>(slab0 + (int64_t)sidx * (BM * BN) + lm * BN + ln);
+        vu += *reinterpret_cast<const f32x4*>(slab0 + (int64_t)sidx * (BM * BN) + lm * BN + 128 + ln);
+      }
+      const float ra = p.alpha * (p.rowscale_part ? p.rowscale_r[mg] : 1.f);
+      bf16x4_bits o, og, ou;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        og[e] = (short)f2bf(vg[e] * ra); ou[e] = (short)f2bf(vu[e] * ra);
+        o[e] = (short)f2bf(bfround(silu(bf2f((bf16_bits)og[e]))) * bf2f((bf16_bits)ou[e]));
+      }
+      *reinterpret_cast<bf16x4_bits*>(p.C + (int64_t)mg * p.ldc + ng) = o;
+      if (p.Cpre) {
+        *reinterpret_cast<bf16x4_bits*>(p.Cpre + (int64_t)mg * p.N + ng) = og;
+        *reinterpret_cast<bf16x4_bits*>(p.Cpre + (int64_t)mg * p.N + F + ng) = ou;
+      }
+      continue;
+    }
     const int m = m0 + lm, n = n0 + ln;
     if (m >= p.M || n >= p.N) continue;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -1922,11 +1961,12 @@ int launch_w4(GemmParams& p, hipStream_t stream, int64_t ws_bytes, bool hybrid) 
   p.tiles_m = cdiv(p.M, BM);
   p.tiles_n = GMAP ? (p.N / 2) / 128 : cdiv(p.N, BN);
   if (GMAP) {
-    if ((p.N % 256) != 0 || p.split_k > 1 || p.rowsq_out || p.bias || p.residual || p.colscale || p.Cpre || p.film_gamma || p.dact_src || p.rope_cos) {
-      ovla_set_error("ovla_gemm_bf16: act = OVLA_ACT_SWIGLU needs N = 2 F with F %% 128 == 0 and nothing else in the epilogue but alpha / the RMSNorm-fold row scale");
+    if ((p.N % 256) != 0 || p.split_k > 1 || p.rowsq_out || p.bias || p.residual || p.colscale || p.film_gamma || p.dact_src || p.rope_cos ||
+        (p.Cpre && ((((uintptr_t)p.Cpre) & 15) != 0 || (p.N % 8) != 0)) || (p.k2_group_n > 0 && p.k2_group_n != p.N / 2)) {
+      ovla_set_error("ovla_gemm_bf16: act = OVLA_ACT_SWIGLU needs N = 2 F with F %% 128 == 0, a K-extension grouped by F (or not at all) and nothing else in the epilogue but alpha, "
+                     "the RMSNorm-fold row scale and C_pre (the [M, 2 F] projection output)");
       return OVLA_EINVAL;
     }
-    hybrid = false;   // (the remainder reduce knows nothing of gate | up pairs: whole tiles only)
   }
   const int splits = p.split_k > 1 ? p.split_k : 1;
   const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(bf16_bits) + (WNW == 4 ? 128 * sizeof(float) : 0);   // + s_rstd of the RMSNorm fold
@@ -2073,7 +2113,8 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
   int tile = a->tile % 1000;
   const int64_t wsb = a->workspace ? a->workspace_bytes : 0;
   if (a->act == OVLA_ACT_SWIGLU)
-    OVLA_REQUIRE((tile == 22 || tile == 122) && a->ldc >= a->N / 2, "ovla_gemm_bf16: act = OVLA_ACT_SWIGLU (C [M, N / 2] = silu(gate) * up of the stacked [gate; up] projection) runs on tile 22 / 122 only");
+    OVLA_REQUIRE((tile == 0 || tile == 18 || tile == 118 || tile == 22 || tile == 122) && a->ldc >= a->N / 2 && (a->K % BK) == 0,
+                 "ovla_gemm_bf16: act = OVLA_ACT_SWIGLU (C [M, N / 2] = silu(gate) * up of the stacked [gate; up] projection) runs on the 4-wave configurations only (tile 0 / 18 / 118 / 22 / 122, K %% 64 == 0)");
   bool hybrid = false;
   if (tile == 0) {
     // auto schedule.  Skinny outputs (LoRA t / dt, N <= 128) and small M (action head) are HBM-bound weight/activation
@@ -2093,7 +2134,8 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
       OVLA_CHECK_LAUNCH("ovla_gemm_bf16(skinny)");
       return OVLA_OK;
     }
-    if (p.N <= 32 || p.a_group_n == 32) { tile = 5; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 128) * cdiv(p.N, 32)); }
+    if (a->act == OVLA_ACT_SWIGLU) { tile = 18; hybrid = true; }
+    else if (p.N <= 32 || p.a_group_n == 32) { tile = 5; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 128) * cdiv(p.N, 32)); }
     else if (p.a_group_n > 0) { tile = 1; }
     else if (p.M <= 64 || p.N <= 128) { tile = 2; if (p.split_k <= 1) p.split_k = want_split(cdiv(p.M, 64) * cdiv(p.N, 128)); }
     else {   // 256x256 / 128x128 / 64x128 / 128x32 tiles, whichever the hybrid-schedule cost model predicts fastest
@@ -2161,6 +2203,12 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     case 117: return launch_cfg<256, 256, 2, 4>(p, stream, wsb, true);
     case 18: case 118: {   // 4-wave 256x256, register-staged operands, hand-scheduled K loop
       const bool hy = hybrid || tile == 118;
+      if (p.act == OVLA_ACT_SWIGLU) {   // the SwiGLU pair map on the 256x256 tile (the fine-tune step's gate | up projection: LoRA rank 32, C_pre = the projection output)
+        if (p.K2 == 0) return launch_w4<0, 0, 2, false, true>(p, stream, wsb, hy);
+        if (p.K2 == 32) return launch_w4<1, 0, 2, false, true>(p, stream, wsb, hy);
+        ovla_set_error("ovla_gemm_bf16: act = OVLA_ACT_SWIGLU takes a K-extension of 0 or 32 columns, not %d", p.K2);
+        return OVLA_EINVAL;
+      }
       switch (p.K2) {
         case 0: return launch_w4<0>(p, stream, wsb, hy);
         case 32: return launch_w4<1>(p, stream, wsb, hy);
@@ -2171,9 +2219,9 @@ extern "C" int ovla_gemm_bf16(const ovla_gemm_args* a, void* stream_) {
     }
     case 22: case 122: {   // 128x256 tile on 1 x 4 waves of 128x64, the same hand-scheduled loop (batch-1 shapes: M = 608 = 4.75 row tiles)
       const bool hy = hybrid || tile == 122;
-      if (p.act == OVLA_ACT_SWIGLU) {   // the SwiGLU pair map (no K-extension)
-        if (p.K2 != 0) { ovla_set_error("ovla_gemm_bf16: act = OVLA_ACT_SWIGLU takes no K-extension"); return OVLA_EINVAL; }
-        return launch_w4<0, 0, 4, false, true>(p, stream, wsb, false);
+      if (p.act == OVLA_ACT_SWIGLU) {   // the SwiGLU pair map (no K-extension on this tile)
+        if (p.K2 != 0) { ovla_set_error("ovla_gemm_bf16: on the 128x256 config act = OVLA_ACT_SWIGLU takes no K-extension"); return OVLA_EINVAL; }
+        return launch_w4<0, 0, 4, false, true>(p, stream, wsb, hy);
       }
       if (p.rope_cos) {   // the RoPE column map (only without a K-extension: the merged / adapter-free decoder of the batch-1 chunk)
         if (p.K2 != 0) { ovla_set_error("ovla_gemm_bf16: the 128x256 config fuses RoPE only without a K-extension"); return OVLA_EINVAL; }

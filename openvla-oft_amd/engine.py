@@ -55,6 +55,10 @@ _ASYNC_UPLOAD = os.environ.get("OVLA_ASYNC_UPLOAD", "1") != "0"
 _FOLD_RMSNORM = os.environ.get("OVLA_FOLD_RMSNORM", "1") != "0"
 # OVLA_INFER_W4=0: the folded inference path's projections take the planner's tile instead of the 4-wave 128x256 configuration (A/B switch of LlamaStack._infer_tile)
 _INFER_W4 = os.environ.get("OVLA_INFER_W4", "1") != "0"
+# OVLA_FUSE_SWIGLU_FWD=1: the decoder's gate|up projection and SwiGLU become one launch in the unfolded forward too (OVLA_ACT_SWIGLU on the 256x256 tile, C_pre keeps
+# the [M, 2F] projection output for the backward).  Bit-identical; measured neutral on the fine-tune step (158.1 / 158.5 vs 158.0 / 158.0 ms: the read-back that saves
+# the swiglu_fwd launch is itself bound by the tile's stores), so it stays off there; the folded batch-1 path always fuses (LlamaStack._infer_tile).
+_FUSE_SWIGLU_FWD = os.environ.get("OVLA_FUSE_SWIGLU_FWD", "0") == "1"
 # OVLA_LORA_BWD=1: the LoRA backward's dt and dB from ONE pass over dy (csrc/lora_bwd.hip) instead of a skinny NT GEMM (dt) + TN GEMMs (dB, dA).
 # Built, parity-tested and measured in round 3 (tools/lora_bwd_bench.py, cold operands, M = 4864): 293.6 vs 272.4 us per decoder layer for the
 # three-kernel path -- reading dy once saves 0.4 GB per layer, but a 2-D (rows x 256-column) decomposition pays it back as fp32 partial-dt slabs
@@ -531,6 +535,12 @@ class LlamaStack:
         self.folded = True
         self._fold_plan = {}
 
+    def _swiglu_pair_ok(self, lin) -> bool:
+        """OVLA_ACT_SWIGLU's shape rules (ovla.h): F a multiple of 128, K of 64, LoRA rank 32 grouped by F (or merged / absent), no bias."""
+        F, D = self.cfg.llm_ff, self.cfg.llm_dim
+        live = lin.has_lora and not getattr(lin, "merged", False)
+        return F % 128 == 0 and D % 64 == 0 and lin.bias is None and (not live or (lin.r == 32 and lin.groups == 2))
+
     def _infer_tile(self, M: int) -> int:
         """Tile configuration of the folded inference path's four projections.  A few hundred rows (the batch-1 chunk: M = 608 = 4.75 row tiles of 128): the
         4-wave 128x256 configuration with the hand-scheduled K loop (ovla.h tile 122: -9...-16 % per projection on cold weights, tools/cold_gemm_probe.py);
@@ -604,8 +614,14 @@ class LlamaStack:
             else:
                 x2, s_o = l["o"].fwd(o, residual=x)
             h2, _, r2 = ops.norm_fwd(x2, l["n2"], eps=cfg.rms_eps, rms=True, save_stats=train)
-            gu, s_gu = l["gu"].fwd(h2)
-            hm = ops.swiglu_fwd(gu)
+            if _FUSE_SWIGLU_FWD and x2.shape[0] >= 256 and self._swiglu_pair_ok(l["gu"]):
+                # gate|up + SwiGLU in ONE launch (ovla.h OVLA_ACT_SWIGLU on the 4-wave 256x256 configuration): h comes out of the projection's read-back;
+                # the [M, 2F] projection output is still written (C_pre) when the backward needs it, but never read again in the forward
+                gu = torch.empty((x2.shape[0], 2 * F), dtype=BF16, device=x.device) if train else None
+                hm, s_gu = l["gu"].fwd(h2, act=ops.ACT_SWIGLU, c_pre=gu)
+            else:
+                gu, s_gu = l["gu"].fwd(h2)
+                hm = ops.swiglu_fwd(gu)
             x3, s_d = l["down"].fwd(hm, residual=x2)
             if train:
                 saved.append((x, r1, s_qkv, qkv, o, lse, s_o, x2, r2, s_gu, gu, s_d))

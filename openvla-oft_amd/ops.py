@@ -115,7 +115,7 @@ def gemm(a, b, *, out=None, bias=None, act=ACT_NONE, residual=None, colscale=Non
         g.A2, g.lda2, g.B2, g.ldb2, g.K2 = a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), b2.shape[1]
         g.k2_group_n = k2_group_n
     if c_pre is not None:
-        assert c_pre.shape == (M, N) and c_pre.stride(0) == out.stride(0)
+        assert c_pre.shape == (M, N) and c_pre.stride(0) == (N if act == ACT_SWIGLU else out.stride(0))   # ACT_SWIGLU: c_pre = the contiguous [M, 2F] projection output
         g.C_pre = c_pre.data_ptr()
     if bias is not None:
         assert bias.numel() == N

@@ -694,6 +694,28 @@ def test_gemm_swiglu_pair_epilogue(ops, dev, M, F, K, fold):
         ops.gemm(x, w, tile=17, act=ops.ACT_SWIGLU)
 
 
+@pytest.mark.parametrize("M,F,K,tile,lora", [(4864, 1024, 512, 0, True), (2500, 1280, 2048, 118, True), (300, 256, 320 + 64, 18, True), (1000, 640, 192, 18, False),
+                                            (4864, 2816, 1024, 0, True), (608, 1408, 512, 122, False)])
+def test_gemm_swiglu_pair_training_shape(ops, dev, M, F, K, tile, lora):
+    """act = OVLA_ACT_SWIGLU on the 256x256 4-wave configuration, the fine-tune step's gate|up projection: grouped LoRA K-extension (group of the gate rows /
+    of the up rows), C_pre = the [M, 2 F] projection output kept for the backward, in-kernel read-back AND the hybrid-remainder reduce -- bit for bit the
+    projection followed by ovla_swiglu_fwd."""
+    torch.manual_seed(M + F + K)
+    x, w = rnd(M, K, dev=dev, scale=0.5), rnd(2 * F, K, dev=dev, scale=0.1)
+    kw = {}
+    if lora:
+        kw.update(a2=rnd(M, 64, dev=dev), b2=rnd(2 * F, 32, dev=dev, scale=0.2), k2_group_n=F)
+    ptile = {0: 118}.get(tile, tile)
+    gu = ops.gemm(x, w, tile=ptile, **kw)
+    ref = ops.swiglu_fwd(gu)
+    pre = torch.full((M, 2 * F), float("nan"), dtype=BF, device=dev)
+    got = ops.gemm(x, w, tile=tile, act=ops.ACT_SWIGLU, c_pre=pre, **kw)
+    assert got.shape == (M, F) and torch.equal(got, ref), f"h: {(got != ref).sum().item()} of {ref.numel()} differ"
+    assert torch.equal(pre, gu), f"gate|up: {(pre != gu).sum().item()} of {gu.numel()} differ"
+    got2 = ops.gemm(x, w, tile=tile, act=ops.ACT_SWIGLU, **kw)
+    assert torch.equal(got2, ref)
+
+
 @pytest.mark.parametrize("M,S,tile", [(608, 608, 22), (608, 608, 122), (700, 100, 22), (1216, 304, 122), (4864, 608, 122)])
 def test_gemm_rope_epilogue_128x256(ops, dev, M, S, tile):
     """RoPE in the epilogue of the 4-wave 128x256 configuration (its column map for RoPE launches; no K-extension: the merged decoder of the batch-1 chunk)
