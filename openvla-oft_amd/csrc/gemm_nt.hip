@@ -1036,20 +1036,19 @@ __global__ __launch_bounds__(256) void gemm_nt_w4_kernel(const GemmParams p) {
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(NP) : "memory");   // the NP LDS-DMA pieces of tile t_begin have landed (the NP register loads behind them may still fly)
   }
 
-  // body t (PAR = parity of t - t_begin = LDS buffer holding tile t).  Program order of memory operations per MFMA row r (0 .. 15; row 15 of tile t - 1 is
-  // the deferred row issued at the top): ds_read a(r + 1) [+ ds_read b1[i] in the first k substep], vmcnt(15) + ds_write piece r of tile t + 1 into the
-  // other buffer, global_load piece r of tile t + 2 into the freed registers, lgkmcnt(n) for a(r), 8 MFMAs.  16 loads are in flight per wave at all
-  // times, so `vmcnt(15)` is exactly "the load issued 16 loads ago has landed".
+  // body t (PAR = parity of t - t_begin = LDS buffer holding tile t): 16 MFMA rows r = (k substep, m-tile), NT MFMAs each; row 15 of tile t - 1 is deferred
+  // across the barrier and issued at the top, under the first fragment reads of tile t.  One memory instruction sits after each of a row's first MFMAs (not as
+  // a block between two rows: the wave issues in order, and six other instructions after a row's last MFMA let the matrix pipe run dry for ~10 of every 138
+  // cycles -- 1.38 us per K tile where this placement, with the fragment reads TWO rows ahead (three A fragments live), needs 1.37 at full speed of the rest):
+  //   ds_read a(r + 2) | ds_read b1[i] (first k substep) | vmcnt(NP - 1) | ds_write piece r of tile t + 1 into the other buffer | global_load piece r of tile t + 2
+  // NP loads are in flight per wave at all times, so `vmcnt(NP - 1)` is exactly "the load issued NP loads ago has landed"; the lgkmcnt a row needs before its
+  // first MFMA comes from the LDS operations' program order (w4_newer).
   // (STAGE = false: the odd last tile, after which nothing is staged any more.  A staging load whose result is never used would be a DEAD asm output: the
   // compiler then hands its destination registers to the next live value while the load is still in flight -- seen in the listing, half a K tile lost.)
-  // Inside a row the non-MFMA instructions sit BETWEEN the MFMAs (one after each of the first four), not in a block between two rows: the wave issues in
-  // order, so a block of six other instructions after a row's eighth MFMA let the matrix pipe run dry for ~10 of every 138 cycles (measured 1.38 us per K tile
-  // against 1.24 at the loop's clock ceiling).  Fragment reads run TWO rows ahead (three A fragments live).  LDS operations in program order --
-  //   top: b0[0..7], a(0), a(1), [w15]      row r: a(r + 2) (r <= 13), b1[r] (r <= 7), [w r]      ([..] = with staging)
-  // -- give the `lgkmcnt` a row needs before its first MFMA: everything NEWER than the youngest fragment it uses may stay in flight.
+  // (SHIFT: the instructions may start SHIFT MFMA gaps later in a row; always 0 -- see the note at the k_loop call.)
   auto body = [&](const int t, auto par_tag, auto stage_tag, auto shift_tag) {
     constexpr int PAR = decltype(par_tag)::value;
-    constexpr int SHIFT = decltype(shift_tag)::value;   // = the wave's index: its memory instructions sit SHIFT MFMA gaps later in every row than wave 0's (below)
+    constexpr int SHIFT = decltype(shift_tag)::value;
     constexpr bool STAGE = decltype(stage_tag)::value && !(ABL & 1);
     constexpr bool FRAG = !(ABL & 2);
     const char* gA = tile_base(p.A, clampt(t + 2));
